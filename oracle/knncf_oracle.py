@@ -1,0 +1,260 @@
+"""ctypes loader for the CPU oracle (oracle/knncf_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: import this from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg — never from the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libknncf_oracle.so")
+
+SIM_COSINE, SIM_ONE, SIM_JACCARD = 0, 1, 2
+KIND_GLOBAL, KIND_USER, KIND_ITEM, KIND_BASELINE, KIND_BASELINE_SPARK = 0, 1, 2, 3, 4
+
+_i32p = C.POINTER(C.c_int32)
+_f64p = C.POINTER(C.c_double)
+
+
+def build():
+    """Compile the oracle with gcc (idempotent)."""
+    src = os.path.join(_HERE, "knncf_oracle.c")
+    hdr = os.path.join(_HERE, "knncf_oracle.h")
+    if os.path.exists(_LIB_PATH) and os.path.getmtime(_LIB_PATH) >= max(
+        os.path.getmtime(src), os.path.getmtime(hdr)
+    ):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "libknncf_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        build()
+    L = C.CDLL(_LIB_PATH)
+    L.orc_improve.restype = C.c_uint32
+    L.orc_improve.argtypes = [C.c_uint32]
+    L.orc_trie_key.restype = C.c_uint32
+    L.orc_trie_key.argtypes = [C.c_uint32]
+    L.orc_tuple2_hash.restype = C.c_uint32
+    L.orc_tuple2_hash.argtypes = [C.c_int32, C.c_int32]
+    L.orc_int_set_order.restype = None
+    L.orc_int_set_order.argtypes = [_i32p, C.c_int32, _i32p]
+    L.orc_scale.restype = C.c_double
+    L.orc_scale.argtypes = [C.c_double, C.c_double]
+    L.orc_fit.restype = C.c_void_p
+    L.orc_fit.argtypes = [_i32p, _i32p, _f64p, C.c_int64, C.POINTER(C.c_int)]
+    L.orc_free.restype = None
+    L.orc_free.argtypes = [C.c_void_p]
+    L.orc_num_users.restype = C.c_int32
+    L.orc_num_users.argtypes = [C.c_void_p]
+    L.orc_num_items.restype = C.c_int32
+    L.orc_num_items.argtypes = [C.c_void_p]
+    L.orc_user_iteration_order.restype = None
+    L.orc_user_iteration_order.argtypes = [C.c_void_p, _i32p]
+    L.orc_average.restype = C.c_double
+    L.orc_average.argtypes = [C.c_void_p]
+    for name in ("orc_users_avg", "orc_items_avg", "orc_items_avg_dev", "orc_items_avg_dev_spark",
+                 "orc_user_weight"):
+        f = getattr(L, name)
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_int32, _f64p]
+    L.orc_normalized_deviations.restype = _f64p
+    L.orc_normalized_deviations.argtypes = [C.c_void_p]
+    L.orc_preprocessed.restype = _f64p
+    L.orc_preprocessed.argtypes = [C.c_void_p]
+    for name in ("orc_predict_global", "orc_predict_user_avg", "orc_predict_item_avg",
+                 "orc_predict_item_avg_dev", "orc_predict_baseline", "orc_predict_baseline_spark"):
+        f = getattr(L, name)
+        f.restype = C.c_double
+        f.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    L.orc_mae_simple.restype = C.c_double
+    L.orc_mae_simple.argtypes = [C.c_void_p, C.c_int, _i32p, _i32p, _f64p, C.c_int64, _f64p]
+    L.orc_pipeline_create.restype = C.c_void_p
+    L.orc_pipeline_create.argtypes = [C.c_void_p, C.c_int, C.c_int32]
+    L.orc_pipeline_free.restype = None
+    L.orc_pipeline_free.argtypes = [C.c_void_p]
+    for name in ("orc_pipeline_raw_similarity", "orc_pipeline_knn_similarity", "orc_pipeline_wsd",
+                 "orc_pipeline_predict"):
+        f = getattr(L, name)
+        f.restype = C.c_double
+        f.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    L.orc_fresh_similarity.restype = C.c_double
+    L.orc_fresh_similarity.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_int32]
+    L.orc_pipeline_neighbors.restype = C.c_int32
+    L.orc_pipeline_neighbors.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _i32p, _f64p]
+    L.orc_pipeline_mae.restype = C.c_double
+    L.orc_pipeline_mae.argtypes = [C.c_void_p, _i32p, _i32p, _f64p, C.c_int64, _f64p]
+    _lib = L
+    return L
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+class OracleError(RuntimeError):
+    def __init__(self, status):
+        super().__init__(f"oracle status {status}")
+        self.status = status
+
+
+def improve(h):
+    return lib().orc_improve(h & 0xFFFFFFFF)
+
+
+def trie_key(h):
+    return lib().orc_trie_key(h & 0xFFFFFFFF)
+
+
+def tuple2_hash(a, b):
+    return lib().orc_tuple2_hash(a, b)
+
+
+def int_set_order(ids):
+    a = _i32(ids)
+    out = np.empty_like(a)
+    lib().orc_int_set_order(_p(a, _i32p), len(a), _p(out, _i32p))
+    return out.tolist()
+
+
+def scale(x, y):
+    return lib().orc_scale(x, y)
+
+
+class Model:
+    """The training set as captured by the reference's closures."""
+
+    def __init__(self, users, items, ratings):
+        self.users, self.items, self.ratings = _i32(users), _i32(items), _f64(ratings)
+        st = C.c_int(0)
+        self._h = lib().orc_fit(_p(self.users, _i32p), _p(self.items, _i32p),
+                                _p(self.ratings, _f64p), len(self.users), C.byref(st))
+        if not self._h:
+            raise OracleError(st.value)
+        self.n = len(self.users)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_free(self._h)
+            self._h = None
+
+    @property
+    def num_users(self):
+        return lib().orc_num_users(self._h)
+
+    @property
+    def num_items(self):
+        return lib().orc_num_items(self._h)
+
+    def user_iteration_order(self):
+        out = np.empty(self.num_users, dtype=np.int32)
+        lib().orc_user_iteration_order(self._h, _p(out, _i32p))
+        return out
+
+    def average(self):
+        return lib().orc_average(self._h)
+
+    def _opt(self, fn, key):
+        v = C.c_double(0)
+        return v.value if fn(self._h, key, C.byref(v)) else None
+
+    def users_avg(self, u):
+        return self._opt(lib().orc_users_avg, u)
+
+    def items_avg(self, i):
+        return self._opt(lib().orc_items_avg, i)
+
+    def items_avg_dev(self, i):
+        return self._opt(lib().orc_items_avg_dev, i)
+
+    def items_avg_dev_spark(self, i):
+        return self._opt(lib().orc_items_avg_dev_spark, i)
+
+    def user_weight(self, u):
+        return self._opt(lib().orc_user_weight, u)
+
+    def normalized_deviations(self):
+        return np.ctypeslib.as_array(lib().orc_normalized_deviations(self._h), shape=(self.n,)).copy()
+
+    def preprocessed(self):
+        return np.ctypeslib.as_array(lib().orc_preprocessed(self._h), shape=(self.n,)).copy()
+
+    def predict(self, kind, u, i):
+        f = [lib().orc_predict_global, lib().orc_predict_user_avg, lib().orc_predict_item_avg,
+             lib().orc_predict_baseline, lib().orc_predict_baseline_spark][kind]
+        return f(self._h, u, i)
+
+    def predict_item_avg_dev(self, u, i):
+        return lib().orc_predict_item_avg_dev(self._h, u, i)
+
+    def mae(self, kind, users, items, ratings, return_predictions=False):
+        u, i, r = _i32(users), _i32(items), _f64(ratings)
+        per = np.empty(len(u), dtype=np.float64)
+        m = lib().orc_mae_simple(self._h, kind, _p(u, _i32p), _p(i, _i32p), _p(r, _f64p), len(u),
+                                 _p(per, _f64p))
+        return (m, per) if return_predictions else m
+
+    def fresh_similarity(self, sim_kind, u, v):
+        return lib().orc_fresh_similarity(self._h, sim_kind, u, v)
+
+    def pipeline(self, sim_kind=SIM_COSINE, k=-1):
+        return Pipeline(self, sim_kind, k)
+
+
+class Pipeline:
+    """predictor(train, weightedSumDeviation(train, F)); F is the similarity
+    itself (k < 0) or getSimilarity(train, k, similarity) (k >= 0)."""
+
+    def __init__(self, model, sim_kind, k):
+        self.model = model
+        self.k = k
+        self._h = lib().orc_pipeline_create(model._h, sim_kind, k)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_pipeline_free(self._h)
+            self._h = None
+
+    def raw_similarity(self, u, v):
+        return lib().orc_pipeline_raw_similarity(self._h, u, v)
+
+    def knn_similarity(self, u, v):
+        return lib().orc_pipeline_knn_similarity(self._h, u, v)
+
+    def neighbors(self, u):
+        cap = max(1, min(self.k if self.k >= 0 else 0, self.model.num_users))
+        ids = np.empty(cap, dtype=np.int32)
+        sims = np.empty(cap, dtype=np.float64)
+        c = lib().orc_pipeline_neighbors(self._h, u, cap, _p(ids, _i32p), _p(sims, _f64p))
+        return ids[:c].copy(), sims[:c].copy()
+
+    def wsd(self, u, i):
+        return lib().orc_pipeline_wsd(self._h, u, i)
+
+    def predict(self, u, i):
+        return lib().orc_pipeline_predict(self._h, u, i)
+
+    def mae(self, users, items, ratings, return_predictions=False):
+        u, i, r = _i32(users), _i32(items), _f64(ratings)
+        per = np.empty(len(u), dtype=np.float64)
+        m = lib().orc_pipeline_mae(self._h, _p(u, _i32p), _p(i, _i32p), _p(r, _f64p), len(u),
+                                   _p(per, _f64p))
+        return (m, per) if return_predictions else m
