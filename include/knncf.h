@@ -1,0 +1,162 @@
+/*
+ * knncf.h — C ABI of the MI355X-native kNN collaborative-filtering engine.
+ *
+ * The reference (EloDoyard/movie-recommender-system) has no FFI boundary: its
+ * hot path is a set of Scala functions in
+ *   src/main/scala/shared/predictions.scala
+ * that take a Seq[Rating]/RDD[Rating] and return (Int,Int)=>Double closures,
+ * called by predict.Baseline, predict.Personalized, predict.kNN and
+ * distributed.DistributedBaseline.  This header is the boundary a JNI shim
+ *  binds instead: one handle == one set of those closures
+ * (including their memo state), plain pointers and sizes only.
+ *
+ * Conventions: every function returns a status (0 ok, negative error; text via
+ * knncf_last_error).  Ids are the RAW user/item ids of the rating files, in
+ * and out.  Host-pointer and device-pointer variants exist for the bulk calls;
+ * "_device" pointers must live on the handle's HIP device.  A handle is not
+ * thread-safe.  The library owns all device memory it allocates.  There is no
+ * CPU fallback: without a usable gfx950 device knncf_create fails.
+ */
+#ifndef KNNCF_H
+#define KNNCF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KNNCF_OK 0
+#define KNNCF_E_INVALID (-1)     /* bad argument */
+#define KNNCF_E_NONFINITE (-2)   /* scale() == 0: non-finite deviation (reference would emit NaN) */
+#define KNNCF_E_DUPLICATE (-3)   /* duplicate (user,item) training rows */
+#define KNNCF_E_NOMEM (-4)
+#define KNNCF_E_HIP (-5)         /* HIP runtime error */
+#define KNNCF_E_STATE (-6)       /* call order, e.g. query before fit */
+#define KNNCF_E_UNSUPPORTED (-7)
+#define KNNCF_E_NODEVICE (-8)    /* no gfx950 device / HIP runtime unavailable */
+
+/* similarity functions of shared/predictions.scala */
+#define KNNCF_SIM_COSINE 0  /* adjustedCosineSimilarityFunction :407-433 */
+#define KNNCF_SIM_ONE 1     /* similarityOne :400 */
+#define KNNCF_SIM_JACCARD 2 /* jaccardCoefficient :440-464 */
+
+/* predictors (the closures the entry points build) */
+#define KNNCF_PRED_GLOBAL_AVG 0   /* computeAvgRating :101 */
+#define KNNCF_PRED_USER_AVG 1     /* computeUserAvg :120 */
+#define KNNCF_PRED_ITEM_AVG 2     /* computeItemAvg :141 */
+#define KNNCF_PRED_BASELINE 3     /* computePrediction :205-237 */
+#define KNNCF_PRED_BASELINE_RDD 4 /* baselinePredictorSpark :362-391 */
+#define KNNCF_PRED_KNN 5          /* predictor(train, weightedSumDeviation(train, getSimilarity(train, k, sim))) predict/kNN.scala:43-44 */
+#define KNNCF_PRED_PERSONALIZED 6 /* predictor(train, weightedSumDeviation(train, sim)) predict/Personalized.scala:61-72 */
+
+#define KNNCF_FLAG_VERIFY_BOUND 1u /* check |approx - exact| <= eps on every re-ranked pair (debug) */
+
+typedef struct knncf_handle knncf_handle;
+
+typedef struct knncf_config {
+    uint32_t struct_size;    /* = sizeof(knncf_config) */
+    int32_t device;          /* HIP device ordinal */
+    int32_t k;               /* neighbourhood size of KNNCF_PRED_KNN (predict/kNN.scala:44 uses 300) */
+    int32_t similarity;      /* KNNCF_SIM_* */
+    int32_t shard_rank;      /* users are block-partitioned over shard_count handles (one per GPU); */
+    int32_t shard_count;     /* this handle owns block shard_rank.  1 = everything. */
+    int64_t workspace_bytes; /* cap for the similarity panel + dense operand panels; 0 = auto */
+    uint32_t flags;          /* KNNCF_FLAG_* */
+    uint32_t reserved;
+} knncf_config;
+
+/* per-stage device timings of the last fit / neighbour build / predict, milliseconds */
+typedef struct knncf_timings {
+    double prep_ms;     /* K0-K4: id compaction, CSR/CSC, means, deviations, norms */
+    double densify_ms;  /* CSR -> bf16 panels */
+    double gemm_ms;     /* K5 similarity GEMM (all launches) */
+    double select_ms;   /* K6 threshold + shortlist */
+    double rerank_ms;   /* K6b exact fp64 re-rank + top-k sort */
+    double predict_ms;  /* K7-K9 prediction + MAE */
+    int64_t gemm_launches;
+    double gemm_flops_executed;    /* 2*M*N*K summed over launches */
+    double gemm_flops_algorithmic; /* 2 * pairs * I_c for the rows built */
+    int64_t shortlist_total;       /* sum of shortlist sizes */
+    int64_t fallback_rows;         /* rows re-done by the exact fallback */
+    double max_bound_violation;    /* KNNCF_FLAG_VERIFY_BOUND: max(|approx-exact| - eps), <= 0 when the bound holds */
+} knncf_timings;
+
+const char* knncf_version(void);
+const char* knncf_status_string(int status);
+
+int knncf_create(const knncf_config* cfg, knncf_handle** out);
+void knncf_destroy(knncf_handle* h);
+const char* knncf_last_error(const knncf_handle* h);
+
+/* ---- fit: everything the reference's closures compute eagerly (K0-K4) ----- */
+/* Rows are the collected Array[Rating] in FILE ORDER (the reference's summation
+ * order and fallbacks depend on it).  Arrays are copied. */
+int knncf_fit(knncf_handle* h, const int32_t* users, const int32_t* items,
+              const double* ratings, int64_t n);
+int knncf_fit_device(knncf_handle* h, const int32_t* d_users, const int32_t* d_items,
+                     const double* d_ratings, int64_t n);
+
+int knncf_num_users(const knncf_handle* h, int32_t* out);
+int knncf_num_items(const knncf_handle* h, int32_t* out);
+
+/* ---- scalar queries mirroring the JSON answers ---------------------------- */
+int knncf_global_avg(knncf_handle* h, double* out);                 /* average :94 */
+int knncf_user_avg(knncf_handle* h, int32_t user, double* out);     /* computeUserAvg(train)(user, _) */
+int knncf_item_avg(knncf_handle* h, int32_t item, double* out);     /* computeItemAvg(train)(_, item) */
+int knncf_item_avg_dev(knncf_handle* h, int32_t item, double* out); /* computeItemAvgDev(train)(_, item) :193 */
+/* the similarity function on a fresh closure: sim(train)(u, v) */
+int knncf_similarity(knncf_handle* h, int32_t u, int32_t v, double* out);
+/* getSimilarity(train, k, sim)(u, v): sim if v is one of u's k nearest, else 0 :634-648 */
+int knncf_knn_similarity(knncf_handle* h, int32_t u, int32_t v, double* out);
+/* getNeighbors(train, k, sim)(u): ids and similarities in reference order :603-616 */
+int knncf_neighbors(knncf_handle* h, int32_t u, int32_t cap, int32_t* ids, double* sims,
+                    int32_t* count);
+int knncf_predict(knncf_handle* h, int predictor, int32_t user, int32_t item, double* out);
+
+/* ---- batch ---------------------------------------------------------------- */
+int knncf_predict_batch(knncf_handle* h, int predictor, const int32_t* users,
+                        const int32_t* items, int64_t n, double* out);
+int knncf_predict_batch_device(knncf_handle* h, int predictor, const int32_t* d_users,
+                               const int32_t* d_items, int64_t n, double* d_out);
+/* MAE :69-73 over (users, items, ratings) in file order */
+int knncf_mae(knncf_handle* h, int predictor, const int32_t* users, const int32_t* items,
+              const double* ratings, int64_t n, double* mae);
+/* device variant; returns the partial sums of the rows this shard owns
+ * (rows of users outside the shard are skipped): mae = sum_abs_err / count
+ * after an all-reduce over the shards.  d_pred (optional, may be NULL) receives
+ * the per-row predictions of the owned rows (others untouched). */
+int knncf_mae_device(knncf_handle* h, int predictor, const int32_t* d_users,
+                     const int32_t* d_items, const double* d_ratings, int64_t n,
+                     double* sum_abs_err, int64_t* count, double* d_pred);
+
+/* ---- multi-GPU exchange (one handle per GPU, collectives done by the host) - */
+/* After knncf_fit* on every shard, each shard holds the per-user means/norms
+ * and the per-rating deviations of ITS users only.  The host all-gathers the
+ * segments below (RCCL all-gather over xGMI) in place, then calls
+ * knncf_shard_commit.  With shard_count == 1 these are no-ops. */
+typedef struct knncf_shard_view {
+    int32_t user_begin, user_end; /* owned dense users [begin, end) */
+    int64_t nnz_begin, nnz_end;   /* their entries in the user-major rating arrays */
+    int32_t num_users;
+    int64_t num_ratings;
+    double* d_user_avg;  /* [num_users]   */
+    double* d_user_norm; /* [num_users]   */
+    double* d_dev;       /* [num_ratings] normalized deviations, user-major order */
+    double* d_pre;       /* [num_ratings] preprocessed ratings, user-major order */
+} knncf_shard_view;
+int knncf_shard_view_get(knncf_handle* h, knncf_shard_view* out);
+int knncf_shard_commit(knncf_handle* h);
+
+/* ---- introspection for bench / tests -------------------------------------- */
+int knncf_get_timings(const knncf_handle* h, knncf_timings* out);
+int knncf_reset_timings(knncf_handle* h);
+/* drop the getNeighbors/getSimilarity memo (== constructing fresh closures) */
+int knncf_reset_neighbors(knncf_handle* h);
+/* change k (== getSimilarity(train, k, ...) with a new k); drops the memo */
+int knncf_set_k(knncf_handle* h, int32_t k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,696 @@
+// api.cpp — the C ABI of include/knncf.h: handle, orchestration of K0-K9 on one HIP stream,
+// scalar queries.  No CPU arithmetic path exists here: every number an entry point returns was
+// produced by the HIP kernels (prep.hip, gemm.hip, select.hip, predict.hip).
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "engine.h"
+
+using namespace knncf;
+
+namespace knncf {
+// small kernels of the orchestrator (neighbours.hip)
+void launch_first_rows(int64_t n, const int32_t* d_du, const int32_t* d_di, int32_t own_lo, int32_t own_hi,
+                       uint32_t* d_first, hipStream_t st);
+void launch_collect_new(int32_t U, const uint32_t* d_first, int64_t* d_seq, int64_t epoch, int32_t* d_list,
+                        int32_t* d_count, hipStream_t st);
+void launch_fallback_keys(int32_t U, const double* d_exact, uint64_t* d_keys, uint32_t* d_vals, hipStream_t st);
+void launch_fallback_write(int32_t user, int32_t take, int32_t kcap, const uint32_t* d_sorted_vals,
+                           const double* d_exact, int32_t* nbr_idx, double* nbr_sim, int32_t* nbr_cnt,
+                           hipStream_t st);
+void launch_jaccard_pair(const Train& tr, int32_t u, int32_t v, double* d_out, hipStream_t st);
+}  // namespace knncf
+
+struct StageTimer {
+    hipEvent_t a, b;
+    double* acc;
+};
+
+struct knncf_handle {
+    knncf_config cfg{};
+    hipStream_t stream = nullptr;
+    std::string err;
+    Train tr;
+    PrepScratch prep;
+    bool fitted = false, committed = false;
+    NeighborTable nt;
+    int64_t epoch = 1;
+    // panels
+    int64_t U_pad = 0, K_pad = 0;
+    DArr<bf16_t> Bpanel, Apanel;
+    bool b_ready = false;
+    DArr<float> S;
+    SelectScratch sel;
+    DArr<int32_t> build_list, build_count;
+    DArr<uint32_t> first_row;
+    // test scratch
+    DArr<int32_t> t_du, t_di, t_users, t_items;
+    DArr<double> t_pred, t_err, t_ratings, t_partial, scalar_out;
+    DArr<uint8_t> t_owned;
+    DArr<int64_t> t_counts;
+    // host mirrors for scalar queries
+    std::vector<uint32_t> h_ukeys, h_ikeys;
+    std::vector<int32_t> h_uid;
+    knncf_timings tm{};
+    std::vector<StageTimer> pending;
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace {
+
+hipEvent_t get_event(knncf_handle* h) {
+    if (!h->event_pool.empty()) {
+        hipEvent_t e = h->event_pool.back();
+        h->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    KN_HIP(hipEventCreate(&e));
+    return e;
+}
+
+struct Stage {  // RAII: times a stage of device work on the handle's stream
+    knncf_handle* h;
+    StageTimer t;
+    Stage(knncf_handle* h_, double* acc) : h(h_) {
+        t.a = get_event(h);
+        t.b = get_event(h);
+        t.acc = acc;
+        (void)hipEventRecord(t.a, h->stream);
+    }
+    ~Stage() {
+        (void)hipEventRecord(t.b, h->stream);
+        h->pending.push_back(t);
+    }
+};
+
+void resolve_timers(knncf_handle* h) {
+    if (h->pending.empty()) return;
+    (void)hipStreamSynchronize(h->stream);
+    for (auto& t : h->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) *t.acc += ms;
+        h->event_pool.push_back(t.a);
+        h->event_pool.push_back(t.b);
+    }
+    h->pending.clear();
+}
+
+template <class F>
+int guarded(knncf_handle* h, F&& f) {
+    if (!h) return KNNCF_E_INVALID;
+    try {
+        KN_HIP(hipSetDevice(h->cfg.device));
+        f();
+        resolve_timers(h);
+        return KNNCF_OK;
+    } catch (const Error& e) {
+        h->err = e.what();
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipGetLastError();
+        h->pending.clear();
+        return e.status;
+    } catch (const std::bad_alloc&) {
+        h->err = "host allocation failed";
+        return KNNCF_E_NOMEM;
+    } catch (const std::exception& e) {
+        h->err = e.what();
+        return KNNCF_E_INVALID;
+    }
+}
+
+void require_fitted(knncf_handle* h, bool committed = true) {
+    KN_REQUIRE(h->fitted, KNNCF_E_STATE, "call knncf_fit first");
+    if (committed) KN_REQUIRE(h->committed, KNNCF_E_STATE, "sharded handle: call knncf_shard_commit after the exchange");
+}
+
+void load_host_ids(knncf_handle* h) {
+    if (!h->h_ukeys.empty() || h->tr.U == 0) return;
+    Train& tr = h->tr;
+    h->h_ukeys.resize(tr.U);
+    h->h_ikeys.resize(tr.I);
+    h->h_uid.resize(tr.U);
+    KN_HIP(hipMemcpyAsync(h->h_ukeys.data(), tr.ukeys.p, tr.U * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    KN_HIP(hipMemcpyAsync(h->h_ikeys.data(), tr.ikeys.p, tr.I * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    KN_HIP(hipMemcpyAsync(h->h_uid.data(), tr.uid.p, tr.U * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    KN_HIP(hipStreamSynchronize(h->stream));
+}
+
+int32_t dense_user(knncf_handle* h, int32_t raw) {
+    load_host_ids(h);
+    return dense_lookup(h->h_ukeys.data(), h->tr.U, raw);
+}
+int32_t dense_item(knncf_handle* h, int32_t raw) {
+    load_host_ids(h);
+    return dense_lookup(h->h_ikeys.data(), h->tr.I, raw);
+}
+
+template <class T>
+T fetch(knncf_handle* h, const T* d, int64_t idx) {
+    T v;
+    KN_HIP(hipMemcpyAsync(&v, d + idx, sizeof(T), hipMemcpyDeviceToHost, h->stream));
+    KN_HIP(hipStreamSynchronize(h->stream));
+    return v;
+}
+
+void reset_neighbors(knncf_handle* h) {
+    Train& tr = h->tr;
+    NeighborTable& nt = h->nt;
+    nt.k = h->cfg.k;
+    nt.kcap = std::max(0, std::min(nt.k, tr.U - 1));
+    size_t cells = (size_t)tr.U * (size_t)std::max(nt.kcap, 1);
+    nt.idx.ensure(cells);
+    nt.sim.ensure(cells);
+    nt.cnt.ensure(tr.U);
+    nt.seq.ensure(tr.U);
+    KN_HIP(hipMemsetAsync(nt.cnt.p, 0, tr.U * sizeof(int32_t), h->stream));
+    KN_HIP(hipMemsetAsync(nt.seq.p, 0xff, tr.U * sizeof(int64_t), h->stream));  // -1
+    h->epoch = 1;
+}
+
+// per-pair error bound of the bf16 GEMM entry, excluding the per-row accumulation term that
+// select.hip adds from the row length: both operands rounded to bf16 (u = 2^-8, via fp32),
+// products exact in fp32, sum |x y| <= ||x|| ||y|| <= 1
+float gemm_eps_base() {
+    const double u = ldexp(1.0, -8) * 1.001;
+    return (float)(2 * u + u * u);
+}
+
+int32_t shortlist_cap(int32_t k, int32_t U) {
+    int64_t want = std::max<int64_t>(2 * (int64_t)k, (int64_t)k + 1024);
+    int64_t cap = 64;
+    while (cap < want) cap <<= 1;
+    int64_t upper = 64;
+    while (upper < U) upper <<= 1;
+    return (int32_t)std::min(cap, upper);
+}
+
+// build the neighbourhoods of the users in h->build_list[0 .. count)
+void build_neighbors(knncf_handle* h, int32_t count) {
+    Train& tr = h->tr;
+    NeighborTable& nt = h->nt;
+    if (count <= 0 || nt.kcap <= 0) return;
+    KN_REQUIRE(h->cfg.similarity == KNNCF_SIM_COSINE, KNNCF_E_UNSUPPORTED,
+               "kNN neighbourhoods are built for the adjusted-cosine similarity only");
+    hipStream_t st = h->stream;
+    h->U_pad = round_up(tr.U, 128);
+    h->K_pad = round_up(tr.I, 64);
+    const int64_t U_pad = h->U_pad, K_pad = h->K_pad;
+    size_t free_b = 0, total_b = 0;
+    KN_HIP(hipMemGetInfo(&free_b, &total_b));
+    if (!h->b_ready) {
+        size_t need = (size_t)U_pad * K_pad * sizeof(bf16_t);
+        KN_REQUIRE(need < free_b + h->Bpanel.bytes(), KNNCF_E_UNSUPPORTED,
+                   "dense bf16 user panel does not fit in HBM; column-panelled build is not implemented yet");
+        Stage s(h, &h->tm.densify_ms);
+        h->Bpanel.ensure((size_t)U_pad * K_pad);
+        launch_densify(tr, nullptr, 0, tr.U, nullptr, h->Bpanel.p, K_pad, U_pad, st);
+        h->b_ready = true;
+        KN_HIP(hipMemGetInfo(&free_b, &total_b));
+    }
+    // rows per block from the similarity-panel budget
+    int64_t budget = h->cfg.workspace_bytes > 0 ? h->cfg.workspace_bytes
+                                                : (int64_t)std::min<size_t>((size_t)16 << 30, (free_b + h->S.bytes() + h->Apanel.bytes()) / 3);
+    int64_t per_row = U_pad * 4 + K_pad * 2;
+    int64_t R = std::max<int64_t>(128, (budget / per_row) / 128 * 128);
+    R = std::min<int64_t>(R, round_up(count, 128));
+    h->S.ensure((size_t)R * U_pad);
+    h->Apanel.ensure((size_t)R * K_pad);
+    const int32_t cap = shortlist_cap(nt.k, tr.U);
+    const bool verify = (h->cfg.flags & KNNCF_FLAG_VERIFY_BOUND) != 0;
+    h->sel.cand_idx.ensure((size_t)R * cap);
+    if (verify) h->sel.cand_approx.ensure((size_t)R * cap);
+    h->sel.cand_cnt.ensure(R);
+    h->sel.stats.ensure(4);
+    const float eps = gemm_eps_base();
+    std::vector<int32_t> h_cnt;
+    for (int64_t rb = 0; rb < count; rb += R) {
+        const int32_t rows = (int32_t)std::min<int64_t>(R, count - rb);
+        const int64_t M = round_up(rows, 128);
+        const int32_t* d_rows = h->build_list.p + rb;
+        {
+            Stage s(h, &h->tm.densify_ms);
+            launch_densify(tr, d_rows, 0, rows, nullptr, h->Apanel.p, K_pad, M, st);
+        }
+        {
+            Stage s(h, &h->tm.gemm_ms);
+            launch_gemm_nt(h->Apanel.p, h->Bpanel.p, h->S.p, M, U_pad, K_pad, K_pad, K_pad, U_pad, st);
+            h->tm.gemm_launches += 1;
+            h->tm.gemm_flops_executed += 2.0 * (double)M * (double)U_pad * (double)K_pad;
+            h->tm.gemm_flops_algorithmic += 2.0 * (double)rows * (double)(tr.U - 1) * (double)tr.I;
+        }
+        {
+            Stage s(h, &h->tm.select_ms);
+            launch_select(h->S.p, U_pad, rows, d_rows, tr.u_ptr.p, tr.U, nt.k, eps, cap, h->sel.cand_idx.p,
+                          verify ? h->sel.cand_approx.p : nullptr, h->sel.cand_cnt.p, st);
+        }
+        {
+            Stage s(h, &h->tm.rerank_ms);
+            launch_rerank(tr, nt, rows, d_rows, cap, h->sel.cand_idx.p, h->sel.cand_approx.p, h->sel.cand_cnt.p, eps,
+                          h->sel.stats.p, verify, st);
+        }
+        // rows whose shortlist overflowed: exact row + stable descending sort (rare)
+        h_cnt.resize(rows);
+        KN_HIP(hipMemcpyAsync(h_cnt.data(), h->sel.cand_cnt.p, rows * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        KN_HIP(hipStreamSynchronize(st));
+        std::vector<int32_t> h_rows;
+        for (int32_t r = 0; r < rows; ++r) {
+            h->tm.shortlist_total += std::min(h_cnt[r], cap);
+            if (h_cnt[r] > cap) {
+                if (h_rows.empty()) {
+                    h_rows.resize(rows);
+                    KN_HIP(hipMemcpyAsync(h_rows.data(), d_rows, rows * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+                    KN_HIP(hipStreamSynchronize(st));
+                }
+                Stage s(h, &h->tm.rerank_ms);
+                int32_t u = h_rows[r];
+                h->sel.row_exact.ensure(tr.U);
+                h->sel.fb_keys_a.ensure(tr.U); h->sel.fb_keys_b.ensure(tr.U);
+                h->sel.fb_vals_a.ensure(tr.U); h->sel.fb_vals_b.ensure(tr.U);
+                int64_t seq_u = fetch(h, nt.seq.p, u);
+                launch_exact_row(tr, nt, u, seq_u, h->sel.row_exact.p, st);
+                launch_fallback_keys(tr.U, h->sel.row_exact.p, h->sel.fb_keys_a.p, h->sel.fb_vals_a.p, st);
+                sort_pairs_u64_u32(h->prep.sort, h->sel.fb_keys_a.p, h->sel.fb_keys_b.p, h->sel.fb_vals_a.p,
+                                   h->sel.fb_vals_b.p, tr.U, 64, st);
+                launch_fallback_write(u, nt.kcap, nt.kcap, h->sel.fb_vals_b.p, h->sel.row_exact.p, nt.idx.p, nt.sim.p,
+                                      nt.cnt.p, st);
+                h->tm.fallback_rows += 1;
+            }
+        }
+    }
+    if (verify) {
+        unsigned long long bits = 0;
+        KN_HIP(hipMemcpyAsync(&bits, h->sel.stats.p, sizeof(bits), hipMemcpyDeviceToHost, st));
+        KN_HIP(hipStreamSynchronize(st));
+        if (bits != 0) {
+            double shifted;
+            memcpy(&shifted, &bits, sizeof(double));
+            h->tm.max_bound_violation = std::max(h->tm.max_bound_violation, shifted - 4.0);
+        }
+    }
+}
+
+void ensure_test_scratch(knncf_handle* h, int64_t n) {
+    h->t_du.ensure(n); h->t_di.ensure(n); h->t_pred.ensure(n); h->t_err.ensure(n); h->t_owned.ensure(n);
+    h->t_partial.ensure(1024); h->t_counts.ensure(1024);
+}
+
+// neighbourhoods needed by the test rows, in the order the reference's lazy closures would build
+// them: a user's neighbourhood is built at its first test row whose item has raters
+void ensure_neighbors_for_rows(knncf_handle* h, int64_t n) {
+    Train& tr = h->tr;
+    if (tr.U < 2 || h->nt.kcap <= 0) return;
+    KN_REQUIRE(n < (int64_t)0xffffffffll, KNNCF_E_UNSUPPORTED, "more than 2^32-1 test rows");
+    hipStream_t st = h->stream;
+    h->first_row.ensure(tr.U);
+    h->build_list.ensure(tr.U);
+    h->build_count.ensure(1);
+    KN_HIP(hipMemsetAsync(h->first_row.p, 0xff, tr.U * sizeof(uint32_t), st));
+    KN_HIP(hipMemsetAsync(h->build_count.p, 0, sizeof(int32_t), st));
+    launch_first_rows(n, h->t_du.p, h->t_di.p, tr.own_lo, tr.own_hi, h->first_row.p, st);
+    launch_collect_new(tr.U, h->first_row.p, h->nt.seq.p, h->epoch, h->build_list.p, h->build_count.p, st);
+    h->epoch += 1;
+    int32_t count = fetch(h, h->build_count.p, 0);
+    build_neighbors(h, count);
+}
+
+void run_predict(knncf_handle* h, int predictor, const int32_t* d_users, const int32_t* d_items,
+                 const double* d_ratings, int64_t n, double* sum_abs_err, int64_t* count, double* d_pred_out) {
+    require_fitted(h);
+    Train& tr = h->tr;
+    hipStream_t st = h->stream;
+    KN_REQUIRE(n >= 0, KNNCF_E_INVALID, "negative row count");
+    if (sum_abs_err) *sum_abs_err = 0.0;
+    if (count) *count = 0;
+    if (n == 0) return;
+    KN_REQUIRE(d_users && d_items, KNNCF_E_INVALID, "null test arrays");
+    int kind = predictor;
+    if (predictor == KNNCF_PRED_PERSONALIZED) {
+        KN_REQUIRE(h->cfg.similarity == KNNCF_SIM_ONE, KNNCF_E_UNSUPPORTED,
+                   "PERSONALIZED without a neighbourhood is built for similarityOne only; use KNN with k >= U-1 for cosine");
+        kind = KNNCF_PRED_BASELINE_RDD;  // num/den = file-order mean of the item's deviations (see predict.hip)
+    }
+    KN_REQUIRE(kind >= KNNCF_PRED_GLOBAL_AVG && kind <= KNNCF_PRED_KNN, KNNCF_E_INVALID, "unknown predictor");
+    ensure_test_scratch(h, n);
+    {
+        Stage s(h, &h->tm.predict_ms);
+        launch_dense_ids(tr, d_users, d_items, n, h->t_du.p, h->t_di.p, st);
+    }
+    if (kind == KNNCF_PRED_KNN) ensure_neighbors_for_rows(h, n);
+    {
+        Stage s(h, &h->tm.predict_ms);
+        double* pred = d_pred_out ? d_pred_out : h->t_pred.p;
+        launch_predict(tr, &h->nt, kind, n, h->t_du.p, h->t_di.p, d_ratings, nullptr, pred, h->t_err.p, h->t_owned.p,
+                       h->cfg.shard_rank == 0, st);
+        if (sum_abs_err || count) {
+            const int32_t nb = 1024;
+            launch_reduce_err(h->t_err.p, h->t_owned.p, n, h->t_partial.p, h->t_counts.p, nb, st);
+            std::vector<double> hp(nb);
+            std::vector<int64_t> hc(nb);
+            KN_HIP(hipMemcpyAsync(hp.data(), h->t_partial.p, nb * sizeof(double), hipMemcpyDeviceToHost, st));
+            KN_HIP(hipMemcpyAsync(hc.data(), h->t_counts.p, nb * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+            KN_HIP(hipStreamSynchronize(st));
+            double s_ = 0.0;
+            int64_t c_ = 0;
+            for (int32_t b = 0; b < nb; ++b) { s_ += hp[b]; c_ += hc[b]; }
+            if (sum_abs_err) *sum_abs_err = s_;
+            if (count) *count = c_;
+        }
+    }
+}
+
+void do_fit_device(knncf_handle* h, const int32_t* d_users, const int32_t* d_items, const double* d_ratings, int64_t n) {
+    KN_REQUIRE(n > 0 && d_users && d_items && d_ratings, KNNCF_E_INVALID, "fit: null or empty input");
+    Train& tr = h->tr;
+    hipStream_t st = h->stream;
+    h->fitted = h->committed = false;
+    h->b_ready = false;
+    h->h_ukeys.clear(); h->h_ikeys.clear(); h->h_uid.clear();
+    tr.n = n;
+    {
+        Stage s(h, &h->tm.prep_ms);
+        if (tr.user_raw.p != d_users) {
+            tr.user_raw.alloc(n); tr.item_raw.alloc(n); tr.rating.alloc(n);
+            KN_HIP(hipMemcpyAsync(tr.user_raw.p, d_users, n * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+            KN_HIP(hipMemcpyAsync(tr.item_raw.p, d_items, n * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+            KN_HIP(hipMemcpyAsync(tr.rating.p, d_ratings, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+        }
+        prep_fit(tr, h->prep, h->cfg.shard_rank, h->cfg.shard_count, st);
+    }
+    h->fitted = true;
+    reset_neighbors(h);
+    if (h->cfg.shard_count == 1) {
+        Stage s(h, &h->tm.prep_ms);
+        prep_commit(tr, h->prep, st);
+        h->committed = true;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* knncf_version(void) { return "knncf 0.1 (gfx950)"; }
+
+const char* knncf_status_string(int st) {
+    switch (st) {
+        case KNNCF_OK: return "ok";
+        case KNNCF_E_INVALID: return "invalid argument";
+        case KNNCF_E_NONFINITE: return "non-finite normalized deviation";
+        case KNNCF_E_DUPLICATE: return "duplicate (user,item) rating";
+        case KNNCF_E_NOMEM: return "out of memory";
+        case KNNCF_E_HIP: return "HIP runtime error";
+        case KNNCF_E_STATE: return "invalid call order";
+        case KNNCF_E_UNSUPPORTED: return "unsupported configuration";
+        case KNNCF_E_NODEVICE: return "no usable gfx950 device";
+        default: return "unknown status";
+    }
+}
+
+int knncf_create(const knncf_config* cfg, knncf_handle** out) {
+    if (!cfg || !out || cfg->struct_size != sizeof(knncf_config)) return KNNCF_E_INVALID;
+    if (cfg->shard_count < 1 || cfg->shard_rank < 0 || cfg->shard_rank >= cfg->shard_count || cfg->k < 0)
+        return KNNCF_E_INVALID;
+    if (cfg->similarity < KNNCF_SIM_COSINE || cfg->similarity > KNNCF_SIM_JACCARD) return KNNCF_E_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
+        (void)hipGetLastError();
+        return KNNCF_E_NODEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return KNNCF_E_NODEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return KNNCF_E_NODEVICE;  // CDNA4 code objects only
+    knncf_handle* h = new (std::nothrow) knncf_handle();
+    if (!h) return KNNCF_E_NOMEM;
+    h->cfg = *cfg;
+    if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return KNNCF_E_HIP;
+    }
+    *out = h;
+    return KNNCF_OK;
+}
+
+void knncf_destroy(knncf_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    (void)hipStreamSynchronize(h->stream);
+    for (auto& t : h->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    for (auto e : h->event_pool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+const char* knncf_last_error(const knncf_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int knncf_fit_device(knncf_handle* h, const int32_t* d_users, const int32_t* d_items, const double* d_ratings, int64_t n) {
+    return guarded(h, [&] { do_fit_device(h, d_users, d_items, d_ratings, n); });
+}
+
+int knncf_fit(knncf_handle* h, const int32_t* users, const int32_t* items, const double* ratings, int64_t n) {
+    return guarded(h, [&] {
+        KN_REQUIRE(n > 0 && users && items && ratings, KNNCF_E_INVALID, "fit: null or empty input");
+        Train& tr = h->tr;
+        tr.user_raw.alloc(n); tr.item_raw.alloc(n); tr.rating.alloc(n);
+        KN_HIP(hipMemcpyAsync(tr.user_raw.p, users, n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        KN_HIP(hipMemcpyAsync(tr.item_raw.p, items, n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        KN_HIP(hipMemcpyAsync(tr.rating.p, ratings, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        do_fit_device(h, tr.user_raw.p, tr.item_raw.p, tr.rating.p, n);
+    });
+}
+
+int knncf_num_users(const knncf_handle* h, int32_t* out) {
+    if (!h || !out || !h->fitted) return KNNCF_E_STATE;
+    *out = h->tr.U;
+    return KNNCF_OK;
+}
+int knncf_num_items(const knncf_handle* h, int32_t* out) {
+    if (!h || !out || !h->fitted) return KNNCF_E_STATE;
+    *out = h->tr.I;
+    return KNNCF_OK;
+}
+
+int knncf_global_avg(knncf_handle* h, double* out) {
+    return guarded(h, [&] {
+        require_fitted(h, false);
+        KN_REQUIRE(out, KNNCF_E_INVALID, "null out");
+        *out = h->tr.global_avg;
+    });
+}
+
+int knncf_user_avg(knncf_handle* h, int32_t user, double* out) {
+    return guarded(h, [&] {
+        require_fitted(h);
+        KN_REQUIRE(out, KNNCF_E_INVALID, "null out");
+        int32_t d = dense_user(h, user);
+        *out = d >= 0 ? fetch(h, h->tr.user_avg.p, d) : h->tr.global_avg;
+    });
+}
+
+int knncf_item_avg(knncf_handle* h, int32_t item, double* out) {
+    return guarded(h, [&] {
+        require_fitted(h);
+        KN_REQUIRE(out, KNNCF_E_INVALID, "null out");
+        int32_t d = dense_item(h, item);
+        *out = d >= 0 ? fetch(h, h->tr.item_avg.p, d) : h->tr.global_avg;
+    });
+}
+
+int knncf_item_avg_dev(knncf_handle* h, int32_t item, double* out) {
+    return guarded(h, [&] {
+        require_fitted(h);
+        KN_REQUIRE(out, KNNCF_E_INVALID, "null out");
+        int32_t d = dense_item(h, item);
+        *out = d >= 0 ? fetch(h, h->tr.item_dev_hash.p, d) : 0.0;
+    });
+}
+
+int knncf_similarity(knncf_handle* h, int32_t u, int32_t v, double* out) {
+    return guarded(h, [&] {
+        require_fitted(h);
+        KN_REQUIRE(out, KNNCF_E_INVALID, "null out");
+        if (h->cfg.similarity == KNNCF_SIM_ONE) { *out = 1.0; return; }
+        int32_t du = dense_user(h, u), dv = dense_user(h, v);
+        h->scalar_out.ensure(1);
+        if (h->cfg.similarity == KNNCF_SIM_JACCARD) {
+            launch_jaccard_pair(h->tr, du, dv, h->scalar_out.p, h->stream);
+        } else {
+            if (du < 0 || dv < 0) { *out = 0.0; return; }
+            launch_exact_pair(h->tr, du, dv, h->scalar_out.p, h->stream);
+        }
+        *out = fetch(h, h->scalar_out.p, 0);
+    });
+}
+
+static void neighbors_of(knncf_handle* h, int32_t du, std::vector<int32_t>& ids, std::vector<double>& sims) {
+    NeighborTable& nt = h->nt;
+    Train& tr = h->tr;
+    ids.clear(); sims.clear();
+    if (tr.U < 2 || nt.kcap <= 0) return;
+    int64_t seq = fetch(h, nt.seq.p, du);
+    if (seq < 0) {
+        h->build_list.ensure(tr.U);
+        int64_t new_seq = h->epoch << 32;
+        h->epoch += 1;
+        KN_HIP(hipMemcpyAsync(nt.seq.p + du, &new_seq, sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+        KN_HIP(hipMemcpyAsync(h->build_list.p, &du, sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        KN_HIP(hipStreamSynchronize(h->stream));
+        build_neighbors(h, 1);
+    }
+    int32_t cnt = fetch(h, nt.cnt.p, du);
+    ids.resize(cnt); sims.resize(cnt);
+    if (cnt > 0) {
+        KN_HIP(hipMemcpyAsync(ids.data(), nt.idx.p + (int64_t)du * nt.kcap, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        KN_HIP(hipMemcpyAsync(sims.data(), nt.sim.p + (int64_t)du * nt.kcap, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        KN_HIP(hipStreamSynchronize(h->stream));
+    }
+}
+
+int knncf_neighbors(knncf_handle* h, int32_t u, int32_t cap, int32_t* ids, double* sims, int32_t* count) {
+    return guarded(h, [&] {
+        require_fitted(h);
+        KN_REQUIRE(count && cap >= 0 && (cap == 0 || (ids && sims)), KNNCF_E_INVALID, "bad output arguments");
+        KN_REQUIRE(h->cfg.similarity == KNNCF_SIM_COSINE, KNNCF_E_UNSUPPORTED, "neighbourhoods: adjusted cosine only");
+        int32_t du = dense_user(h, u);
+        load_host_ids(h);
+        if (du < 0) {  // user absent from train: every similarity is 0.0, ties keep Set order (N3)
+            int32_t c = std::min(h->nt.k, h->tr.U);
+            for (int32_t j = 0; j < c && j < cap; ++j) { ids[j] = h->h_uid[j]; sims[j] = 0.0; }
+            *count = c;
+            return;
+        }
+        KN_REQUIRE(du >= h->tr.own_lo && du < h->tr.own_hi, KNNCF_E_INVALID, "user belongs to another shard");
+        std::vector<int32_t> di;
+        std::vector<double> ds;
+        neighbors_of(h, du, di, ds);
+        for (size_t j = 0; j < di.size() && (int32_t)j < cap; ++j) { ids[j] = h->h_uid[di[j]]; sims[j] = ds[j]; }
+        *count = (int32_t)di.size();
+    });
+}
+
+int knncf_knn_similarity(knncf_handle* h, int32_t u, int32_t v, double* out) {
+    return guarded(h, [&] {
+        require_fitted(h);
+        KN_REQUIRE(out, KNNCF_E_INVALID, "null out");
+        KN_REQUIRE(h->cfg.similarity == KNNCF_SIM_COSINE, KNNCF_E_UNSUPPORTED, "neighbourhoods: adjusted cosine only");
+        int32_t du = dense_user(h, u), dv = dense_user(h, v);
+        *out = 0.0;
+        if (du < 0 || dv < 0) return;  // all of an unseen user's similarities are 0.0
+        KN_REQUIRE(du >= h->tr.own_lo && du < h->tr.own_hi, KNNCF_E_INVALID, "user belongs to another shard");
+        std::vector<int32_t> di;
+        std::vector<double> ds;
+        neighbors_of(h, du, di, ds);
+        for (size_t j = 0; j < di.size(); ++j)
+            if (di[j] == dv) { *out = 0.0 + ds[j]; break; }
+    });
+}
+
+int knncf_predict_batch_device(knncf_handle* h, int predictor, const int32_t* d_users, const int32_t* d_items,
+                               int64_t n, double* d_out) {
+    return guarded(h, [&] {
+        KN_REQUIRE(d_out || n == 0, KNNCF_E_INVALID, "null output");
+        run_predict(h, predictor, d_users, d_items, nullptr, n, nullptr, nullptr, d_out);
+    });
+}
+
+int knncf_predict_batch(knncf_handle* h, int predictor, const int32_t* users, const int32_t* items, int64_t n, double* out) {
+    return guarded(h, [&] {
+        KN_REQUIRE(n >= 0 && (n == 0 || (users && items && out)), KNNCF_E_INVALID, "bad arguments");
+        if (n == 0) return;
+        h->t_users.ensure(n); h->t_items.ensure(n); h->t_pred.ensure(n);
+        KN_HIP(hipMemcpyAsync(h->t_users.p, users, n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        KN_HIP(hipMemcpyAsync(h->t_items.p, items, n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        run_predict(h, predictor, h->t_users.p, h->t_items.p, nullptr, n, nullptr, nullptr, nullptr);
+        KN_HIP(hipMemcpyAsync(out, h->t_pred.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        KN_HIP(hipStreamSynchronize(h->stream));
+    });
+}
+
+int knncf_predict(knncf_handle* h, int predictor, int32_t user, int32_t item, double* out) {
+    return knncf_predict_batch(h, predictor, &user, &item, 1, out);
+}
+
+int knncf_mae_device(knncf_handle* h, int predictor, const int32_t* d_users, const int32_t* d_items,
+                     const double* d_ratings, int64_t n, double* sum_abs_err, int64_t* count, double* d_pred) {
+    return guarded(h, [&] {
+        KN_REQUIRE(sum_abs_err && count && (n == 0 || d_ratings), KNNCF_E_INVALID, "bad arguments");
+        run_predict(h, predictor, d_users, d_items, d_ratings, n, sum_abs_err, count, d_pred);
+    });
+}
+
+int knncf_mae(knncf_handle* h, int predictor, const int32_t* users, const int32_t* items, const double* ratings,
+              int64_t n, double* mae) {
+    return guarded(h, [&] {
+        KN_REQUIRE(mae && n >= 0 && (n == 0 || (users && items && ratings)), KNNCF_E_INVALID, "bad arguments");
+        KN_REQUIRE(h->cfg.shard_count == 1, KNNCF_E_STATE, "sharded handle: use knncf_mae_device and all-reduce the partial sums");
+        if (n == 0) { *mae = NAN; return; }  // 0.0 / 0 in applyAndMean :85
+        h->t_users.ensure(n); h->t_items.ensure(n); h->t_ratings.ensure(n);
+        KN_HIP(hipMemcpyAsync(h->t_users.p, users, n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        KN_HIP(hipMemcpyAsync(h->t_items.p, items, n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        KN_HIP(hipMemcpyAsync(h->t_ratings.p, ratings, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        double s = 0.0;
+        int64_t c = 0;
+        run_predict(h, predictor, h->t_users.p, h->t_items.p, h->t_ratings.p, n, &s, &c, nullptr);
+        *mae = s / (double)n;
+    });
+}
+
+int knncf_shard_view_get(knncf_handle* h, knncf_shard_view* out) {
+    return guarded(h, [&] {
+        require_fitted(h, false);
+        KN_REQUIRE(out, KNNCF_E_INVALID, "null out");
+        Train& tr = h->tr;
+        out->user_begin = tr.own_lo;
+        out->user_end = tr.own_hi;
+        out->nnz_begin = fetch(h, tr.u_ptr.p, tr.own_lo);
+        out->nnz_end = fetch(h, tr.u_ptr.p, tr.own_hi);
+        out->num_users = tr.U;
+        out->num_ratings = tr.n;
+        out->d_user_avg = tr.user_avg.p;
+        out->d_user_norm = tr.user_norm.p;
+        out->d_dev = tr.s_dev.p;
+        out->d_pre = tr.s_pre.p;
+    });
+}
+
+int knncf_shard_commit(knncf_handle* h) {
+    return guarded(h, [&] {
+        require_fitted(h, false);
+        if (h->committed) return;
+        Stage s(h, &h->tm.prep_ms);
+        prep_commit(h->tr, h->prep, h->stream);
+        h->committed = true;
+    });
+}
+
+int knncf_get_timings(const knncf_handle* h, knncf_timings* out) {
+    if (!h || !out) return KNNCF_E_INVALID;
+    *out = h->tm;
+    return KNNCF_OK;
+}
+
+int knncf_reset_timings(knncf_handle* h) {
+    if (!h) return KNNCF_E_INVALID;
+    h->tm = knncf_timings{};
+    return KNNCF_OK;
+}
+
+int knncf_reset_neighbors(knncf_handle* h) {
+    return guarded(h, [&] {
+        require_fitted(h, false);
+        reset_neighbors(h);
+    });
+}
+
+int knncf_set_k(knncf_handle* h, int32_t k) {
+    return guarded(h, [&] {
+        KN_REQUIRE(k >= 0, KNNCF_E_INVALID, "negative k");
+        h->cfg.k = k;
+        if (h->fitted) reset_neighbors(h);
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,133 @@
+// engine.h — internal state of one knncf handle and the launcher interface between the host
+// orchestrator (api.cpp) and the kernel translation units.  gfx950 only.
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace knncf {
+
+typedef __bf16 bf16_t;
+
+// ---- sort_util.hip (rocPRIM device radix sort / unique; K0 plumbing only) ---------------
+struct SortWorkspace {
+    DArr<char> tmp;
+};
+void sort_pairs_u64_u32(SortWorkspace& ws, const uint64_t* kin, uint64_t* kout, const uint32_t* vin,
+                        uint32_t* vout, size_t n, int end_bit, hipStream_t st);
+void sort_keys_u32(SortWorkspace& ws, const uint32_t* kin, uint32_t* kout, size_t n, hipStream_t st);
+// out must hold n entries; returns the number of distinct values (synchronises the stream)
+size_t unique_u32(SortWorkspace& ws, const uint32_t* sorted_in, uint32_t* out, size_t n, hipStream_t st);
+
+// ---- prep.hip: K0-K4 -------------------------------------------------------------------
+struct Train {
+    int64_t n = 0;
+    int32_t U = 0, I = 0;
+    // raw rows, file order
+    DArr<int32_t> user_raw, item_raw;
+    DArr<double> rating;
+    // dense ids: trie keys of the distinct raw ids, in dense order (see dense_lookup)
+    DArr<uint32_t> ukeys, ikeys;
+    DArr<int32_t> uid, iid;  // raw id of dense index
+    // canonical user-major order ("position" p): users ascending, inside a user items ascending.
+    // dense item index == rank in HashSet iteration order, so ascending p inside a user IS the
+    // reference's summation order N2 for users with > 4 ratings.
+    DArr<int64_t> u_ptr;     // [U+1]
+    DArr<int32_t> s_user;    // [n]
+    DArr<int32_t> s_col;     // [n]
+    DArr<uint32_t> s_t;      // [n] file row of position p
+    DArr<double> s_rating;   // [n]
+    DArr<double> s_dev;      // [n] computeNormalizeDeviation :155-169
+    DArr<double> s_pre;      // [n] preprocessedRating :470-481
+    // fold orders (permutations of positions)
+    DArr<uint32_t> perm_uf;  // (user, file order)            usersAvg :113
+    DArr<uint32_t> perm_uh;  // (user, HashMap order, N4)      usersWeights :474
+    DArr<uint32_t> perm_if;  // (item, file order)            itemsAvg :134 / Spark :336-343
+    DArr<uint32_t> perm_ih;  // (item, HashMap order, N4)      itemsAvgDev :176-186
+    DArr<int64_t> i_ptr;     // [I+1]
+    DArr<double> user_avg, user_norm;  // [U]
+    DArr<double> item_avg, item_dev_hash, item_dev_file;  // [I]
+    double global_avg = 0.0;
+    int32_t own_lo = 0, own_hi = 0;  // owned dense users [lo, hi)
+};
+
+// status word bits written by kernels
+enum : uint32_t { ST_NONFINITE = 1u, ST_DUPLICATE = 2u, ST_NOT_DYADIC = 4u };
+
+struct PrepScratch {
+    SortWorkspace sort;
+    DArr<uint64_t> k64_a, k64_b;
+    DArr<uint32_t> v32_a, v32_b, k32_a, k32_b;
+    DArr<int32_t> du_row, di_row;
+    DArr<uint32_t> perm_f;
+    DArr<uint32_t> status;  // [4] device status words
+    DArr<double> dsum;      // small reduction scratch
+    void release_all();
+};
+
+// K0 + K1 + owned part of K2/K3.  Throws Error on invalid data.
+void prep_fit(Train& tr, PrepScratch& sc, int32_t shard_rank, int32_t shard_count, hipStream_t st);
+// item-side folds (need every user's deviations): K4
+void prep_commit(Train& tr, PrepScratch& sc, hipStream_t st);
+
+// raw test ids -> dense (-1 = absent from train)
+void launch_dense_ids(const Train& tr, const int32_t* d_users, const int32_t* d_items, int64_t n,
+                      int32_t* d_du, int32_t* d_di, hipStream_t st);
+
+// ---- gemm.hip: densify + K5 ------------------------------------------------------------
+// rows[r] = dense user of panel row r (nullptr: panel row r == user row_begin + r)
+void launch_densify(const Train& tr, const int32_t* d_rows, int32_t row_begin, int32_t n_rows,
+                    const int32_t* d_colmap, bf16_t* panel, int64_t ld, int64_t panel_rows,
+                    hipStream_t st);
+// C[M][ldc] (fp32) = A[M][K] * B[N][K]^T, bf16 in / fp32 accumulate; M, N multiples of 128, K of 64
+void launch_gemm_nt(const bf16_t* A, const bf16_t* B, float* C, int64_t M, int64_t N, int64_t K,
+                    int64_t lda, int64_t ldb, int64_t ldc, hipStream_t st);
+
+// ---- select.hip: K6 + K6b --------------------------------------------------------------
+struct NeighborTable {
+    int32_t k = 0;     // requested k
+    int32_t kcap = 0;  // min(k, U-1): stored neighbours per user
+    DArr<int32_t> idx;   // [U * kcap] dense neighbour ids, reference order
+    DArr<double> sim;    // [U * kcap]
+    DArr<int32_t> cnt;   // [U] 0 until built
+    DArr<int64_t> seq;   // [U] build sequence number (memo history); -1 = not built
+};
+
+struct SelectScratch {
+    DArr<int32_t> cand_idx;   // [rows * cap]
+    DArr<float> cand_approx;  // [rows * cap] (KNNCF_FLAG_VERIFY_BOUND)
+    DArr<int32_t> cand_cnt;   // [rows] (> cap == overflow)
+    DArr<double> stats;       // [4]: max bound violation, ...
+    DArr<double> row_exact;   // fallback: [U] exact similarities of one row
+    DArr<uint64_t> fb_keys_a, fb_keys_b;
+    DArr<uint32_t> fb_vals_a, fb_vals_b;
+};
+
+// threshold + shortlist for panel rows [0, n_rows): candidates v with S[r][v] >= T_r - 2 eps
+void launch_select(const float* S, int64_t lds, int32_t n_rows, const int32_t* d_row_user,
+                   const int64_t* d_u_ptr, int32_t U, int32_t k, float eps, int32_t cap, int32_t* cand_idx,
+                   float* cand_approx, int32_t* cand_cnt, hipStream_t st);
+// exact fp64 similarities of the shortlists in reference order, stable top-k
+void launch_rerank(const Train& tr, NeighborTable& nt, int32_t n_rows, const int32_t* d_row_user,
+                   int32_t cap, const int32_t* cand_idx, const float* cand_approx,
+                   const int32_t* cand_cnt, float eps, double* d_stats, bool verify, hipStream_t st);
+// exact similarities of one user against everyone (fallback + scalar queries)
+void launch_exact_row(const Train& tr, const NeighborTable& nt, int32_t user, int64_t user_seq,
+                      double* d_out, hipStream_t st);
+// fresh-closure similarity of one pair (owner order = u): writes *d_out
+void launch_exact_pair(const Train& tr, int32_t u, int32_t v, double* d_out, hipStream_t st);
+
+// ---- predict.hip: K7-K9 ----------------------------------------------------------------
+// per test row: prediction of `predictor`; rows whose user is outside [own_lo, own_hi) are
+// skipped (unknown users belong to shard 0).  d_abs_err[t] = |r - p| or 0 for skipped rows.
+void launch_predict(const Train& tr, const NeighborTable* nt, int predictor, int64_t n,
+                    const int32_t* d_du, const int32_t* d_di, const double* d_ratings,
+                    const uint32_t* d_order, double* d_pred, double* d_abs_err, uint8_t* d_owned,
+                    bool unknown_users_owned, hipStream_t st);
+// deterministic fixed-shape reduction: sum of d_abs_err and count of d_owned
+void launch_reduce_err(const double* d_abs_err, const uint8_t* d_owned, int64_t n, double* d_partials,
+                       int64_t* d_counts, int32_t n_blocks, hipStream_t st);
+
+}  // namespace knncf

@@ -1,0 +1,172 @@
+// gemm.hip — K5: the user x user adjusted-cosine similarity as a blocked MFMA GEMM on gfx950.
+//
+//   S[M x N] (fp32) = A[M x K] * B[N x K]^T,  A/B = rows of the preprocessed-rating matrix
+//   rounded to bf16 (both operands K-contiguous: the "NT" form, ideal for LDS staging).
+//
+// The bf16 result only has to be a FILTER: select.hip keeps every candidate within a rigorous
+// error band of the k-th value and the fp64 re-rank decides.
+//
+// Kernel structure (v1): 128x128 block tile, BK = 64, 256 threads = 4 waves as 2x2, each wave a
+// 64x64 sub-tile = 2x2 v_mfma_f32_32x32x16_bf16 accumulators (64 acc VGPRs).  Operand tiles go
+// HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction) into a 2-deep
+// ring; the LDS image is lane-linear as the DMA requires, with the bank swizzle applied on the
+// SOURCE address (16-B chunk c of row r sits in slot c ^ ((r >> 1) & 7), conflict-free for
+// ds_read_b128: the 16 lanes of a read group hit 16 distinct slots of the 256-B bank row).
+// Tile t+1 stays in flight across the barrier behind a counted vmcnt.
+#include "engine.h"
+
+namespace knncf {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// ---- densify -----------------------------------------------------------------------------
+__global__ void k_densify(const int64_t* __restrict__ u_ptr, const int32_t* __restrict__ s_col,
+                          const double* __restrict__ s_pre, const int32_t* __restrict__ rows, int32_t row_begin,
+                          int32_t n_rows, const int32_t* __restrict__ colmap, bf16_t* __restrict__ panel, int64_t ld) {
+    // one wave per panel row
+    int32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    int32_t lane = threadIdx.x & 63;
+    if (wave >= n_rows) return;
+    int32_t u = rows ? rows[wave] : row_begin + wave;
+    int64_t b = u_ptr[u], e = u_ptr[u + 1];
+    bf16_t* out = panel + (int64_t)wave * ld;
+    for (int64_t p = b + lane; p < e; p += 64) {
+        int32_t c = colmap ? colmap[s_col[p]] : s_col[p];
+        if (c >= 0) out[c] = (bf16_t)(float)s_pre[p];
+    }
+}
+
+void launch_densify(const Train& tr, const int32_t* d_rows, int32_t row_begin, int32_t n_rows,
+                    const int32_t* d_colmap, bf16_t* panel, int64_t ld, int64_t panel_rows, hipStream_t st) {
+    KN_HIP(hipMemsetAsync(panel, 0, (size_t)panel_rows * ld * sizeof(bf16_t), st));
+    if (n_rows <= 0) return;
+    int blocks = (int)ceil_div((int64_t)n_rows * 64, 256);
+    k_densify<<<blocks, 256, 0, st>>>(tr.u_ptr.p, tr.s_col.p, tr.s_pre.p, d_rows, row_begin, n_rows, d_colmap, panel, ld);
+    KN_HIP(hipGetLastError());
+}
+
+// ---- GEMM --------------------------------------------------------------------------------
+static constexpr int BM = 128, BN = 128, BK = 64;
+static constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand tile
+static constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // A + B
+static constexpr int LOADS_PER_TILE = TILE_BYTES / 1024 / 4;  // wave-instructions per wave per operand tile = 4
+
+// issue this wave's share of one operand tile (128 rows x 64 bf16) into LDS
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int64_t ld, char* lds_tile, int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < LOADS_PER_TILE; ++j) {
+        int piece = wave * LOADS_PER_TILE + j;       // 1-KiB piece = 8 rows of the tile
+        int row = piece * 8 + (lane >> 3);
+        int slot = lane & 7;
+        int chunk = slot ^ ((row >> 1) & 7);         // swizzle on the source side
+        const bf16_t* src = g + (int64_t)row * ld + chunk * 8;
+        __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(lds_tile + piece * 1024), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int row, int chunk) {
+    int slot = chunk ^ ((row >> 1) & 7);
+    return *reinterpret_cast<const bf16x8*>(lds_tile + row * 128 + slot * 16);
+}
+
+__global__ void __launch_bounds__(256, 2)
+k_gemm_nt_bf16(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, float* __restrict__ C, int tiles_m,
+               int tiles_n, int k_tiles, int64_t lda, int64_t ldb, int64_t ldc) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];  // 2 stages x (A tile + B tile) = 64 KiB
+
+    // XCD-aware tile order: blocks that share an XCD (equal blockIdx % 8, observed round-robin
+    // placement; speed only) walk neighbouring tiles so that A/B panels are reused out of that
+    // XCD's L2.  Bijective remap for any grid size.
+    const int nwg = tiles_m * tiles_n;
+    const int orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    // grouped ordering: 8 tile-rows at a time, column-major inside a group
+    const int GROUP = 8;
+    const int group_sz = GROUP * tiles_n;
+    const int gid = wg / group_sz;
+    const int first_m = gid * GROUP;
+    const int gm = min(GROUP, tiles_m - first_m);
+    const int tm = first_m + (wg % group_sz) % gm;
+    const int tn = (wg % group_sz) / gm;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    const bf16_t* Ag = A + (int64_t)tm * BM * lda;
+    const bf16_t* Bg = B + (int64_t)tn * BN * ldb;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    stage_tile(Ag, lda, lds, wave, lane);
+    stage_tile(Bg, ldb, lds + TILE_BYTES, wave, lane);
+
+    const int frow = lane & 31;  // fragment row inside a 32-row MFMA tile
+    const int fhalf = lane >> 5; // which 8-wide k half of the 16-wide k-step
+
+    for (int kt = 0; kt < k_tiles; ++kt) {
+        char* cur = lds + (kt & 1) * STAGE_BYTES;
+        if (kt + 1 < k_tiles) {
+            char* nxt = lds + ((kt + 1) & 1) * STAGE_BYTES;
+            stage_tile(Ag + (int64_t)(kt + 1) * BK, lda, nxt, wave, lane);
+            stage_tile(Bg + (int64_t)(kt + 1) * BK, ldb, nxt + TILE_BYTES, wave, lane);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // tile kt landed; tile kt+1 (8 DMAs) in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 a0 = read_frag(cur, wr * 64 + frow, ks * 2 + fhalf);
+            bf16x8 a1 = read_frag(cur, wr * 64 + 32 + frow, ks * 2 + fhalf);
+            bf16x8 b0 = read_frag(cur + TILE_BYTES, wc * 64 + frow, ks * 2 + fhalf);
+            bf16x8 b1 = read_frag(cur + TILE_BYTES, wc * 64 + 32 + frow, ks * 2 + fhalf);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // everyone is done reading `cur` before it is restaged
+        asm volatile("" ::: "memory");
+    }
+
+    // C/D layout of v_mfma_f32_32x32x16: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    float* Cg = C + ((int64_t)tm * BM + wr * 64) * ldc + (int64_t)tn * BN + wc * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
+                int col = j * 32 + frow;
+                Cg[(int64_t)row * ldc + col] = acc[i][j][e];
+            }
+}
+
+void launch_gemm_nt(const bf16_t* A, const bf16_t* B, float* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+                    int64_t ldb, int64_t ldc, hipStream_t st) {
+    KN_REQUIRE(M % BM == 0 && N % BN == 0 && K % BK == 0 && K > 0, KNNCF_E_INVALID, "gemm: shape not tile-aligned");
+    KN_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, KNNCF_E_INVALID, "gemm: leading dimensions must be multiples of 8");
+    int64_t tiles = (M / BM) * (N / BN);
+    KN_REQUIRE(tiles > 0 && tiles < (1ll << 31), KNNCF_E_INVALID, "gemm: grid too large");
+    static bool attr_set = false;
+    if (!attr_set) {
+        KN_HIP(hipFuncSetAttribute((const void*)k_gemm_nt_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES));
+        attr_set = true;
+    }
+    k_gemm_nt_bf16<<<(unsigned)tiles, 256, 2 * STAGE_BYTES, st>>>(A, B, C, (int)(M / BM), (int)(N / BN), (int)(K / BK), lda, ldb, ldc);
+    KN_HIP(hipGetLastError());
+}
+
+}  // namespace knncf

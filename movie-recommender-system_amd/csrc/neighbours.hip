@@ -1,0 +1,108 @@
+// neighbours.hip — small orchestration kernels around the neighbourhood build: which users need
+// a neighbourhood and in which order the reference's lazy closures would have built them
+// (SURVEY N6), the exact fallback's ordering keys, and the Jaccard coefficient of one pair.
+#include <math.h>
+
+#include <algorithm>
+
+#include "engine.h"
+
+namespace knncf {
+
+static constexpr int TPB = 256;
+
+// first test row (file order) at which the reference would call nn(u): the user is in train and
+// the item has at least one rater (weightedSumDeviation :508-517 only then evaluates similarities)
+__global__ void k_first_rows(int64_t n, const int32_t* __restrict__ du, const int32_t* __restrict__ di,
+                             int32_t own_lo, int32_t own_hi, uint32_t* __restrict__ first) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    int32_t u = du[t];
+    if (u < own_lo || u >= own_hi || di[t] < 0) return;
+    atomicMin(&first[u], (uint32_t)t);
+}
+
+void launch_first_rows(int64_t n, const int32_t* d_du, const int32_t* d_di, int32_t own_lo, int32_t own_hi,
+                       uint32_t* d_first, hipStream_t st) {
+    if (n <= 0) return;
+    k_first_rows<<<(unsigned)ceil_div(n, TPB), TPB, 0, st>>>(n, d_du, d_di, own_lo, own_hi, d_first);
+    KN_HIP(hipGetLastError());
+}
+
+// users that need a neighbourhood now; their build sequence number orders them like the
+// reference's memo history: (call epoch, first test row)
+__global__ void k_collect_new(int32_t U, const uint32_t* __restrict__ first, int64_t* __restrict__ seq, int64_t epoch,
+                              int32_t* __restrict__ list, int32_t* __restrict__ count) {
+    int32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= U) return;
+    if (first[u] == 0xffffffffu || seq[u] >= 0) return;
+    seq[u] = (epoch << 32) | (int64_t)first[u];
+    list[atomicAdd(count, 1)] = u;
+}
+
+void launch_collect_new(int32_t U, const uint32_t* d_first, int64_t* d_seq, int64_t epoch, int32_t* d_list,
+                        int32_t* d_count, hipStream_t st) {
+    k_collect_new<<<(unsigned)ceil_div(U, TPB), TPB, 0, st>>>(U, d_first, d_seq, epoch, d_list, d_count);
+    KN_HIP(hipGetLastError());
+}
+
+// ascending key order == descending similarity; a stable sort keeps equal similarities in dense
+// (== HashSet iteration) order, i.e. sortWith(_._2 > _._2) on (allUsers - u).toSeq :608-610
+__global__ void k_fallback_keys(int32_t U, const double* __restrict__ exact, uint64_t* __restrict__ keys,
+                                uint32_t* __restrict__ vals) {
+    int32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= U) return;
+    double s = exact[v];
+    if (s == 0.0) s = 0.0;  // -0.0 and +0.0 compare equal in the reference's comparator
+    uint64_t b = (uint64_t)__double_as_longlong(s);
+    uint64_t ordered = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+    keys[v] = ~ordered;
+    vals[v] = (uint32_t)v;
+}
+
+void launch_fallback_keys(int32_t U, const double* d_exact, uint64_t* d_keys, uint32_t* d_vals, hipStream_t st) {
+    k_fallback_keys<<<(unsigned)ceil_div(U, TPB), TPB, 0, st>>>(U, d_exact, d_keys, d_vals);
+    KN_HIP(hipGetLastError());
+}
+
+__global__ void k_fallback_write(int32_t user, int32_t take, int32_t kcap, const uint32_t* __restrict__ sorted_vals,
+                                 const double* __restrict__ exact, int32_t* __restrict__ nbr_idx,
+                                 double* __restrict__ nbr_sim, int32_t* __restrict__ nbr_cnt) {
+    int32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0) nbr_cnt[user] = take;
+    if (j >= take) return;
+    uint32_t v = sorted_vals[j];
+    nbr_idx[(int64_t)user * kcap + j] = (int32_t)v;
+    nbr_sim[(int64_t)user * kcap + j] = exact[v];
+}
+
+void launch_fallback_write(int32_t user, int32_t take, int32_t kcap, const uint32_t* d_sorted_vals,
+                           const double* d_exact, int32_t* nbr_idx, double* nbr_sim, int32_t* nbr_cnt, hipStream_t st) {
+    k_fallback_write<<<(unsigned)ceil_div(std::max(take, 1), TPB), TPB, 0, st>>>(user, take, kcap, d_sorted_vals, d_exact,
+                                                                                 nbr_idx, nbr_sim, nbr_cnt);
+    KN_HIP(hipGetLastError());
+}
+
+// jaccardCoefficient :446-463 (u, v dense or -1 when absent from train)
+__global__ void k_jaccard_pair(const int64_t* __restrict__ u_ptr, const int32_t* __restrict__ s_col, int32_t u,
+                               int32_t v, double* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int64_t pa = 0, ea = 0, pb = 0, eb = 0;
+    if (u >= 0) { pa = u_ptr[u]; ea = u_ptr[u + 1]; }
+    if (v >= 0) { pb = u_ptr[v]; eb = u_ptr[v + 1]; }
+    int64_t nu = ea - pa, nv = eb - pb, both = 0;
+    while (pa < ea && pb < eb) {
+        int32_t ca = s_col[pa], cb = s_col[pb];
+        if (ca == cb) { ++both; ++pa; ++pb; }
+        else if (ca < cb) ++pa;
+        else ++pb;
+    }
+    *out = (double)both / (double)(nu + nv - both);  // 0.0 / 0 -> NaN, as in Scala
+}
+
+void launch_jaccard_pair(const Train& tr, int32_t u, int32_t v, double* d_out, hipStream_t st) {
+    k_jaccard_pair<<<1, 64, 0, st>>>(tr.u_ptr.p, tr.s_col.p, u, v, d_out);
+    KN_HIP(hipGetLastError());
+}
+
+}  // namespace knncf

@@ -1,0 +1,415 @@
+// prep.hip — K0-K4: id compaction, user-major / item-major orders, ordered segmented folds
+// (means, norms, item deviations), normalized deviations and preprocessed ratings.
+//
+// Everything here is HBM-bound integer / fp64 work.  The arithmetic follows
+// shared/predictions.scala operation by operation and IN THE SAME ORDER: sums
+// are left folds along explicit permutations, staged through LDS by coalesced loads and then
+// folded sequentially per segment, so results are bit-identical to the fp64 oracle.
+#include <math.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "engine.h"
+
+namespace knncf {
+
+static constexpr int TPB = 256;
+static inline int nblocks(int64_t n, int per = TPB) { return (int)std::max<int64_t>(1, ceil_div(n, per)); }
+
+void PrepScratch::release_all() {
+    sort.tmp.release();
+    k64_a.release(); k64_b.release(); v32_a.release(); v32_b.release();
+    k32_a.release(); k32_b.release(); du_row.release(); di_row.release(); perm_f.release();
+}
+
+// ---- K0: ids ---------------------------------------------------------------------------
+__global__ void k_row_keys(int64_t n, const int32_t* __restrict__ users, const int32_t* __restrict__ items,
+                           uint32_t* __restrict__ ukey, uint32_t* __restrict__ ikey) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    ukey[t] = int_trie_key(users[t]);
+    ikey[t] = int_trie_key(items[t]);
+}
+
+// first file row of each of <= 4 distinct keys (Set1..Set4 keep insertion order)
+__global__ void k_first_occurrence(int64_t n, const uint32_t* __restrict__ row_key, const uint32_t* __restrict__ keys,
+                                   int32_t count, unsigned long long* __restrict__ first) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    uint32_t k = row_key[t];
+    for (int32_t i = 0; i < count; ++i)
+        if (keys[i] == k) atomicMin(&first[i], (unsigned long long)t);
+}
+
+__global__ void k_dense_ids(int64_t n, const int32_t* __restrict__ users, const int32_t* __restrict__ items,
+                            const uint32_t* __restrict__ ukeys, int32_t U, const uint32_t* __restrict__ ikeys,
+                            int32_t I, int32_t* __restrict__ du, int32_t* __restrict__ di) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    du[t] = dense_lookup(ukeys, U, users[t]);
+    di[t] = dense_lookup(ikeys, I, items[t]);
+}
+
+void launch_dense_ids(const Train& tr, const int32_t* d_users, const int32_t* d_items, int64_t n,
+                      int32_t* d_du, int32_t* d_di, hipStream_t st) {
+    if (n == 0) return;
+    k_dense_ids<<<nblocks(n), TPB, 0, st>>>(n, d_users, d_items, tr.ukeys.p, tr.U, tr.ikeys.p, tr.I, d_du, d_di);
+    KN_HIP(hipGetLastError());
+}
+
+// raw id of every dense index (any row of that user / item carries it)
+__global__ void k_scatter_raw_ids(int64_t n, const int32_t* __restrict__ raw, const int32_t* __restrict__ dense,
+                                  int32_t* __restrict__ out) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    out[dense[t]] = raw[t];
+}
+
+// mode 0: key = du<<32 | di ; 1: du ; 2: du<<32 | tuple key ; 3: di ; 4: di<<32 | tuple key
+__global__ void k_make_keys(int64_t n, int mode, const int32_t* __restrict__ du, const int32_t* __restrict__ di,
+                            const int32_t* __restrict__ users, const int32_t* __restrict__ items,
+                            uint64_t* __restrict__ key) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    uint64_t k;
+    switch (mode) {
+        case 0: k = ((uint64_t)(uint32_t)du[t] << 32) | (uint32_t)di[t]; break;
+        case 1: k = (uint32_t)du[t]; break;
+        case 2: k = ((uint64_t)(uint32_t)du[t] << 32) | tuple_trie_key(users[t], items[t]); break;
+        case 3: k = (uint32_t)di[t]; break;
+        default: k = ((uint64_t)(uint32_t)di[t] << 32) | tuple_trie_key(users[t], items[t]); break;
+    }
+    key[t] = k;
+}
+
+__global__ void k_iota(int64_t n, uint32_t* __restrict__ v) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) v[t] = (uint32_t)t;
+}
+
+// unpack the sorted (user, item) keys; flag duplicate (user, item) rows
+__global__ void k_unpack_positions(int64_t n, const uint64_t* __restrict__ key, int32_t* __restrict__ s_user,
+                                   int32_t* __restrict__ s_col, uint32_t* __restrict__ status) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    uint64_t k = key[p];
+    s_user[p] = (int32_t)(k >> 32);
+    s_col[p] = (int32_t)(k & 0xffffffffu);
+    if (p > 0 && key[p - 1] == k) atomicOr(status, (uint32_t)ST_DUPLICATE);
+}
+
+// ptr[s] = first index whose (key >> shift) >= s, s in [0, S]
+__global__ void k_segment_ptr(int64_t n, const uint64_t* __restrict__ sorted_key, int shift, int32_t S,
+                              int64_t* __restrict__ ptr) {
+    int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > S) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if ((sorted_key[mid] >> shift) < (uint64_t)s) lo = mid + 1;
+        else hi = mid;
+    }
+    ptr[s] = lo;
+}
+
+__global__ void k_gather_f64(int64_t n, const uint32_t* __restrict__ idx, const double* __restrict__ src,
+                             double* __restrict__ dst) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) dst[p] = src[idx[p]];
+}
+
+// perm_f[file row] = position
+__global__ void k_invert(int64_t n, const uint32_t* __restrict__ s_t, uint32_t* __restrict__ perm_f) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) perm_f[s_t[p]] = (uint32_t)p;
+}
+
+// ---- ordered segmented fold ---------------------------------------------------------------
+// out[s] = left fold (0.0 + v0) + v1 ... over the segment's elements in perm order
+// (perm == nullptr: identity).  SQUARE: v = src*src (math.pow(x, 2) in usersWeights :474).
+// One block owns 256 consecutive segments; their element range is staged through LDS in
+// chunks by coalesced loads of perm (+ gather of src), then each thread folds its own
+// segment's part of the chunk sequentially.
+static constexpr int FOLD_CHUNK = 2048;
+
+template <bool SQUARE>
+__global__ void __launch_bounds__(TPB) k_ordered_fold(const int64_t* __restrict__ seg_ptr, int32_t seg_lo,
+                                                      int32_t seg_hi, const uint32_t* __restrict__ perm,
+                                                      const double* __restrict__ src, double* __restrict__ out) {
+    __shared__ double buf[FOLD_CHUNK];
+    int32_t s0 = seg_lo + blockIdx.x * TPB;
+    int32_t s1 = min(s0 + TPB, seg_hi);
+    if (s0 >= seg_hi) return;
+    int32_t s = s0 + threadIdx.x;
+    int64_t e0 = seg_ptr[s0], e1 = seg_ptr[s1];
+    int64_t b = 0, e = 0;
+    if (s < s1) {
+        b = seg_ptr[s];
+        e = seg_ptr[s + 1];
+    }
+    double acc = 0.0;
+    for (int64_t c = e0; c < e1; c += FOLD_CHUNK) {
+        int32_t len = (int32_t)min((int64_t)FOLD_CHUNK, e1 - c);
+        for (int32_t j = threadIdx.x; j < len; j += TPB) {
+            int64_t idx = perm ? (int64_t)perm[c + j] : (c + j);
+            double v = src[idx];
+            buf[j] = SQUARE ? v * v : v;
+        }
+        __syncthreads();
+        int64_t lo = max(b, c), hi = min(e, c + len);
+        for (int64_t q = lo; q < hi; ++q) acc = acc + buf[q - c];
+        __syncthreads();
+    }
+    if (s < s1) out[s] = acc;
+}
+
+// whole-array left fold in index order (average :94 when the ratings are not dyadic)
+__global__ void __launch_bounds__(TPB) k_sequential_sum(int64_t n, const double* __restrict__ src, double* __restrict__ out) {
+    __shared__ double buf[FOLD_CHUNK];
+    double acc = 0.0;
+    for (int64_t c = 0; c < n; c += FOLD_CHUNK) {
+        int32_t len = (int32_t)min((int64_t)FOLD_CHUNK, n - c);
+        for (int32_t j = threadIdx.x; j < len; j += TPB) buf[j] = src[c + j];
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int32_t j = 0; j < len; ++j) acc = acc + buf[j];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = acc;
+}
+
+// ratings that are multiples of 1/16 and small sum EXACTLY in fp64 in any order
+__global__ void k_check_dyadic(int64_t n, const double* __restrict__ r, uint32_t* __restrict__ status) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    double v = r[t] * 16.0;
+    if (!(fabs(v) <= 16777216.0) || v != rint(v)) atomicOr(status, (uint32_t)ST_NOT_DYADIC);
+}
+
+// exact (dyadic) sum: order-free block reduction + atomicAdd, every partial is exact
+__global__ void __launch_bounds__(TPB) k_exact_sum(int64_t n, const double* __restrict__ src, double* __restrict__ out) {
+    __shared__ double red[TPB];
+    double acc = 0.0;
+    for (int64_t t = (int64_t)blockIdx.x * TPB + threadIdx.x; t < n; t += (int64_t)gridDim.x * TPB) acc += src[t];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = TPB / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(out, red[0]);
+}
+
+// mean = sum / count for segments [lo, hi)
+__global__ void k_divide_by_count(const int64_t* __restrict__ seg_ptr, int32_t lo, int32_t hi,
+                                  const double* __restrict__ sum, double* __restrict__ out) {
+    int32_t s = lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= hi) return;
+    out[s] = sum[s] / (double)(seg_ptr[s + 1] - seg_ptr[s]);
+}
+
+__global__ void k_sqrt(int32_t lo, int32_t hi, const double* __restrict__ in, double* __restrict__ out) {
+    int32_t s = lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= hi) return;
+    out[s] = sqrt(in[s]);
+}
+
+// computeNormalizeDeviation :162-168 for positions [p0, p1)
+__global__ void k_deviation(int64_t p0, int64_t p1, const int32_t* __restrict__ s_user,
+                            const double* __restrict__ s_rating, const double* __restrict__ user_avg,
+                            double* __restrict__ s_dev, uint32_t* __restrict__ status) {
+    int64_t p = p0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= p1) return;
+    double r = s_rating[p], ua = user_avg[s_user[p]];
+    double d = (r - ua) / scale_fn(r, ua);
+    s_dev[p] = d;
+    if (!isfinite(d)) atomicOr(status, (uint32_t)ST_NONFINITE);
+}
+
+// preprocessedRating :476-480
+__global__ void k_preprocess(int64_t p0, int64_t p1, const int32_t* __restrict__ s_user,
+                             const double* __restrict__ s_dev, const double* __restrict__ user_norm,
+                             double* __restrict__ s_pre) {
+    int64_t p = p0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= p1) return;
+    double w = user_norm[s_user[p]];
+    s_pre[p] = (w != 0) ? s_dev[p] / w : 0.0;
+}
+
+static int bits_for(uint64_t max_value) {
+    int b = 1;
+    while (b < 64 && (max_value >> b) != 0) ++b;
+    return b;
+}
+
+template <bool SQUARE>
+static void fold(const int64_t* seg_ptr, int32_t lo, int32_t hi, const uint32_t* perm, const double* src,
+                 double* out, hipStream_t st) {
+    if (hi <= lo) return;
+    k_ordered_fold<SQUARE><<<nblocks(hi - lo), TPB, 0, st>>>(seg_ptr, lo, hi, perm, src, out);
+    KN_HIP(hipGetLastError());
+}
+
+static uint32_t read_status(PrepScratch& sc, hipStream_t st) {
+    uint32_t h = 0;
+    KN_HIP(hipMemcpyAsync(&h, sc.status.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    KN_HIP(hipStreamSynchronize(st));
+    return h;
+}
+
+void prep_fit(Train& tr, PrepScratch& sc, int32_t shard_rank, int32_t shard_count, hipStream_t st) {
+    const int64_t n = tr.n;
+    KN_REQUIRE(n > 0, KNNCF_E_INVALID, "fit: empty training set");
+    KN_REQUIRE(n < (int64_t)0xffffffffll, KNNCF_E_UNSUPPORTED, "fit: more than 2^32-1 ratings");
+    sc.status.ensure(4);
+    KN_HIP(hipMemsetAsync(sc.status.p, 0, 4 * sizeof(uint32_t), st));
+    sc.k32_a.ensure(n); sc.k32_b.ensure(n); sc.v32_a.ensure(n); sc.v32_b.ensure(n);
+    sc.k64_a.ensure(n); sc.k64_b.ensure(n);
+
+    // distinct users / items in HashSet iteration order
+    uint32_t* ukey_row = sc.k32_a.p;
+    uint32_t* ikey_row = sc.v32_a.p;
+    k_row_keys<<<nblocks(n), TPB, 0, st>>>(n, tr.user_raw.p, tr.item_raw.p, ukey_row, ikey_row);
+    KN_HIP(hipGetLastError());
+    tr.ukeys.ensure(n);  // shrunk below
+    sort_keys_u32(sc.sort, ukey_row, sc.k32_b.p, n, st);
+    size_t U = unique_u32(sc.sort, sc.k32_b.p, sc.v32_b.p, n, st);
+    tr.ukeys.alloc(U);
+    KN_HIP(hipMemcpyAsync(tr.ukeys.p, sc.v32_b.p, U * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    sort_keys_u32(sc.sort, ikey_row, sc.k32_b.p, n, st);
+    size_t I = unique_u32(sc.sort, sc.k32_b.p, sc.v32_b.p, n, st);
+    tr.ikeys.alloc(I);
+    KN_HIP(hipMemcpyAsync(tr.ikeys.p, sc.v32_b.p, I * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    KN_REQUIRE(U < (1u << 31) && I < (1u << 31), KNNCF_E_UNSUPPORTED, "fit: too many distinct ids");
+    tr.U = (int32_t)U;
+    tr.I = (int32_t)I;
+    if (U <= 4) {  // Set1..Set4: `ratings.map(_.user).toSet` iterates in first-occurrence order (N3)
+        DArr<unsigned long long> first;
+        first.alloc(4);
+        KN_HIP(hipMemsetAsync(first.p, 0xff, 4 * sizeof(unsigned long long), st));
+        k_first_occurrence<<<nblocks(n), TPB, 0, st>>>(n, ukey_row, tr.ukeys.p, tr.U, first.p);
+        KN_HIP(hipGetLastError());
+        unsigned long long hf[4];
+        uint32_t hk[4];
+        KN_HIP(hipMemcpyAsync(hf, first.p, sizeof(hf), hipMemcpyDeviceToHost, st));
+        KN_HIP(hipMemcpyAsync(hk, tr.ukeys.p, U * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        KN_HIP(hipStreamSynchronize(st));
+        std::vector<int> ord(U);
+        for (size_t i = 0; i < U; ++i) ord[i] = (int)i;
+        std::sort(ord.begin(), ord.end(), [&](int a, int b) { return hf[a] < hf[b]; });
+        uint32_t nk[4];
+        for (size_t i = 0; i < U; ++i) nk[i] = hk[ord[i]];
+        KN_HIP(hipMemcpyAsync(tr.ukeys.p, nk, U * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        KN_HIP(hipStreamSynchronize(st));
+    }
+
+    sc.du_row.ensure(n); sc.di_row.ensure(n);
+    k_dense_ids<<<nblocks(n), TPB, 0, st>>>(n, tr.user_raw.p, tr.item_raw.p, tr.ukeys.p, tr.U, tr.ikeys.p, tr.I,
+                                            sc.du_row.p, sc.di_row.p);
+    KN_HIP(hipGetLastError());
+    tr.uid.alloc(U); tr.iid.alloc(I);
+    k_scatter_raw_ids<<<nblocks(n), TPB, 0, st>>>(n, tr.user_raw.p, sc.du_row.p, tr.uid.p);
+    k_scatter_raw_ids<<<nblocks(n), TPB, 0, st>>>(n, tr.item_raw.p, sc.di_row.p, tr.iid.p);
+    KN_HIP(hipGetLastError());
+
+    const int ubits = bits_for(U), ibits = bits_for(I);
+    // canonical user-major order: sort file rows by (user, item)
+    tr.s_user.alloc(n); tr.s_col.alloc(n); tr.s_t.alloc(n); tr.s_rating.alloc(n);
+    tr.s_dev.alloc(n); tr.s_pre.alloc(n); tr.u_ptr.alloc(U + 1); tr.i_ptr.alloc(I + 1);
+    k_make_keys<<<nblocks(n), TPB, 0, st>>>(n, 0, sc.du_row.p, sc.di_row.p, tr.user_raw.p, tr.item_raw.p, sc.k64_a.p);
+    k_iota<<<nblocks(n), TPB, 0, st>>>(n, sc.v32_a.p);
+    KN_HIP(hipGetLastError());
+    sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.v32_a.p, tr.s_t.p, n, 32 + ubits, st);
+    k_unpack_positions<<<nblocks(n), TPB, 0, st>>>(n, sc.k64_b.p, tr.s_user.p, tr.s_col.p, sc.status.p);
+    k_segment_ptr<<<nblocks((int64_t)U + 1), TPB, 0, st>>>(n, sc.k64_b.p, 32, tr.U, tr.u_ptr.p);
+    k_gather_f64<<<nblocks(n), TPB, 0, st>>>(n, tr.s_t.p, tr.rating.p, tr.s_rating.p);
+    sc.perm_f.ensure(n);
+    k_invert<<<nblocks(n), TPB, 0, st>>>(n, tr.s_t.p, sc.perm_f.p);
+    KN_HIP(hipGetLastError());
+
+    // fold orders: stable sorts of the file-order sequence of positions
+    tr.perm_uf.alloc(n); tr.perm_if.alloc(n);
+    k_make_keys<<<nblocks(n), TPB, 0, st>>>(n, 1, sc.du_row.p, sc.di_row.p, tr.user_raw.p, tr.item_raw.p, sc.k64_a.p);
+    sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.perm_f.p, tr.perm_uf.p, n, ubits, st);
+    k_make_keys<<<nblocks(n), TPB, 0, st>>>(n, 3, sc.du_row.p, sc.di_row.p, tr.user_raw.p, tr.item_raw.p, sc.k64_a.p);
+    sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.perm_f.p, tr.perm_if.p, n, ibits, st);
+    k_segment_ptr<<<nblocks((int64_t)I + 1), TPB, 0, st>>>(n, sc.k64_b.p, 0, tr.I, tr.i_ptr.p);
+    KN_HIP(hipGetLastError());
+    if (n > 4) {  // a Map of <= 4 entries (Map1..Map4) iterates in insertion = file order (N4)
+        tr.perm_uh.alloc(n); tr.perm_ih.alloc(n);
+        k_make_keys<<<nblocks(n), TPB, 0, st>>>(n, 2, sc.du_row.p, sc.di_row.p, tr.user_raw.p, tr.item_raw.p, sc.k64_a.p);
+        sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.perm_f.p, tr.perm_uh.p, n, 32 + ubits, st);
+        k_make_keys<<<nblocks(n), TPB, 0, st>>>(n, 4, sc.du_row.p, sc.di_row.p, tr.user_raw.p, tr.item_raw.p, sc.k64_a.p);
+        sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.perm_f.p, tr.perm_ih.p, n, 32 + ibits, st);
+    } else {
+        tr.perm_uh.release();
+        tr.perm_ih.release();
+    }
+
+    // K1: average :94 — left fold over the file; exact in any order for dyadic ratings
+    k_check_dyadic<<<nblocks(n), TPB, 0, st>>>(n, tr.rating.p, sc.status.p);
+    KN_HIP(hipGetLastError());
+    uint32_t status = read_status(sc, st);
+    KN_REQUIRE(!(status & ST_DUPLICATE), KNNCF_E_DUPLICATE, "fit: duplicate (user,item) training rows");
+    sc.dsum.ensure(2);
+    KN_HIP(hipMemsetAsync(sc.dsum.p, 0, 2 * sizeof(double), st));
+    if (status & ST_NOT_DYADIC) k_sequential_sum<<<1, TPB, 0, st>>>(n, tr.rating.p, sc.dsum.p);
+    else k_exact_sum<<<1024, TPB, 0, st>>>(n, tr.rating.p, sc.dsum.p);
+    KN_HIP(hipGetLastError());
+    double total = 0.0;
+    KN_HIP(hipMemcpyAsync(&total, sc.dsum.p, sizeof(double), hipMemcpyDeviceToHost, st));
+    KN_HIP(hipStreamSynchronize(st));
+    tr.global_avg = total / (double)n;
+
+    // owned block of users: ascending dense index, ceil(U / shards) each
+    int32_t per = (int32_t)ceil_div(U, shard_count);
+    tr.own_lo = std::min<int64_t>((int64_t)per * shard_rank, U);
+    tr.own_hi = std::min<int64_t>((int64_t)per * (shard_rank + 1), U);
+    tr.user_avg.alloc(U); tr.user_norm.alloc(U);
+    if (shard_count > 1) {  // the host all-gathers the other shards' segments in place
+        KN_HIP(hipMemsetAsync(tr.user_avg.p, 0, U * sizeof(double), st));
+        KN_HIP(hipMemsetAsync(tr.user_norm.p, 0, U * sizeof(double), st));
+        KN_HIP(hipMemsetAsync(tr.s_dev.p, 0, n * sizeof(double), st));
+        KN_HIP(hipMemsetAsync(tr.s_pre.p, 0, n * sizeof(double), st));
+    }
+    const int32_t lo = tr.own_lo, hi = tr.own_hi;
+    if (hi > lo) {
+        int64_t hp[2];
+        KN_HIP(hipMemcpyAsync(&hp[0], tr.u_ptr.p + lo, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        KN_HIP(hipMemcpyAsync(&hp[1], tr.u_ptr.p + hi, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        KN_HIP(hipStreamSynchronize(st));
+        const int64_t p0 = hp[0], p1 = hp[1];
+        // K2: usersAvg :113 (groupBy keeps file order; mean = reduce(_+_) / length)
+        fold<false>(tr.u_ptr.p, lo, hi, tr.perm_uf.p, tr.s_rating.p, tr.user_norm.p, st);
+        k_divide_by_count<<<nblocks(hi - lo), TPB, 0, st>>>(tr.u_ptr.p, lo, hi, tr.user_norm.p, tr.user_avg.p);
+        // K3: deviations, norms (HashMap order), preprocessed ratings
+        k_deviation<<<nblocks(p1 - p0), TPB, 0, st>>>(p0, p1, tr.s_user.p, tr.s_rating.p, tr.user_avg.p, tr.s_dev.p, sc.status.p);
+        fold<true>(tr.u_ptr.p, lo, hi, n > 4 ? tr.perm_uh.p : tr.perm_uf.p, tr.s_dev.p, tr.user_norm.p, st);
+        k_sqrt<<<nblocks(hi - lo), TPB, 0, st>>>(lo, hi, tr.user_norm.p, tr.user_norm.p);
+        k_preprocess<<<nblocks(p1 - p0), TPB, 0, st>>>(p0, p1, tr.s_user.p, tr.s_dev.p, tr.user_norm.p, tr.s_pre.p);
+        KN_HIP(hipGetLastError());
+    }
+    status = read_status(sc, st);
+    KN_REQUIRE(!(status & ST_NONFINITE), KNNCF_E_NONFINITE,
+               "fit: non-finite normalized deviation (a user's mean is 1 or 5 with a rating beyond it: scale() == 0)");
+}
+
+void prep_commit(Train& tr, PrepScratch& sc, hipStream_t st) {
+    const int64_t n = tr.n;
+    const int32_t I = tr.I;
+    tr.item_avg.alloc(I); tr.item_dev_hash.alloc(I); tr.item_dev_file.alloc(I);
+    sc.dsum.ensure((size_t)I + 2);
+    // itemsAvg :134
+    fold<false>(tr.i_ptr.p, 0, I, tr.perm_if.p, tr.s_rating.p, sc.dsum.p, st);
+    k_divide_by_count<<<nblocks(I), TPB, 0, st>>>(tr.i_ptr.p, 0, I, sc.dsum.p, tr.item_avg.p);
+    // getItemsAvgDev :336-343 (reduceByKey, modelled in file order)
+    fold<false>(tr.i_ptr.p, 0, I, tr.perm_if.p, tr.s_dev.p, sc.dsum.p, st);
+    k_divide_by_count<<<nblocks(I), TPB, 0, st>>>(tr.i_ptr.p, 0, I, sc.dsum.p, tr.item_dev_file.p);
+    // itemsAvgDev :176-186 (foldLeft over the HashMap: trie order of the (user,item) hashes)
+    fold<false>(tr.i_ptr.p, 0, I, n > 4 ? tr.perm_ih.p : tr.perm_if.p, tr.s_dev.p, sc.dsum.p, st);
+    k_divide_by_count<<<nblocks(I), TPB, 0, st>>>(tr.i_ptr.p, 0, I, sc.dsum.p, tr.item_dev_hash.p);
+    KN_HIP(hipGetLastError());
+}
+
+}  // namespace knncf

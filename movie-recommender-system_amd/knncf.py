@@ -1,0 +1,271 @@
+"""ctypes binding of libknncf.so (include/knncf.h).
+
+This is the only door into the engine: there is no Python/NumPy/torch compute path behind it.
+If the shared library is missing or no gfx950 device is usable the calls raise — they never fall
+back to a CPU implementation.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libknncf.so")
+
+OK = 0
+E_INVALID, E_NONFINITE, E_DUPLICATE, E_NOMEM, E_HIP, E_STATE, E_UNSUPPORTED, E_NODEVICE = range(-1, -9, -1)
+SIM_COSINE, SIM_ONE, SIM_JACCARD = 0, 1, 2
+PRED_GLOBAL_AVG, PRED_USER_AVG, PRED_ITEM_AVG, PRED_BASELINE, PRED_BASELINE_RDD, PRED_KNN, PRED_PERSONALIZED = range(7)
+FLAG_VERIFY_BOUND = 1
+
+_i32p = C.POINTER(C.c_int32)
+_f64p = C.POINTER(C.c_double)
+
+
+class Config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("k", C.c_int32),
+                ("similarity", C.c_int32), ("shard_rank", C.c_int32), ("shard_count", C.c_int32),
+                ("workspace_bytes", C.c_int64), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("prep_ms", C.c_double), ("densify_ms", C.c_double), ("gemm_ms", C.c_double),
+                ("select_ms", C.c_double), ("rerank_ms", C.c_double), ("predict_ms", C.c_double),
+                ("gemm_launches", C.c_int64), ("gemm_flops_executed", C.c_double),
+                ("gemm_flops_algorithmic", C.c_double), ("shortlist_total", C.c_int64),
+                ("fallback_rows", C.c_int64), ("max_bound_violation", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class ShardView(C.Structure):
+    _fields_ = [("user_begin", C.c_int32), ("user_end", C.c_int32), ("nnz_begin", C.c_int64),
+                ("nnz_end", C.c_int64), ("num_users", C.c_int32), ("num_ratings", C.c_int64),
+                ("d_user_avg", C.c_void_p), ("d_user_norm", C.c_void_p), ("d_dev", C.c_void_p),
+                ("d_pre", C.c_void_p)]
+
+
+EXPORTS = [
+    "knncf_version", "knncf_status_string", "knncf_create", "knncf_destroy", "knncf_last_error",
+    "knncf_fit", "knncf_fit_device", "knncf_num_users", "knncf_num_items", "knncf_global_avg",
+    "knncf_user_avg", "knncf_item_avg", "knncf_item_avg_dev", "knncf_similarity",
+    "knncf_knn_similarity", "knncf_neighbors", "knncf_predict", "knncf_predict_batch",
+    "knncf_predict_batch_device", "knncf_mae", "knncf_mae_device", "knncf_shard_view_get",
+    "knncf_shard_commit", "knncf_get_timings", "knncf_reset_timings", "knncf_reset_neighbors",
+    "knncf_set_k",
+]
+
+
+class KnncfError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"knncf status {status}: {message}")
+        self.status = status
+
+
+_lib = None
+
+
+def load_library():
+    """Load libknncf.so (built in-tree by build.py).  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            f"{LIB_PATH} not found: build the HIP extension first (python __graft_entry__.py or "
+            f"movie-recommender-system_amd/build.py); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    L.knncf_version.restype = C.c_char_p
+    L.knncf_status_string.restype = C.c_char_p
+    L.knncf_status_string.argtypes = [C.c_int]
+    L.knncf_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+    L.knncf_destroy.argtypes = [C.c_void_p]
+    L.knncf_destroy.restype = None
+    L.knncf_last_error.argtypes = [C.c_void_p]
+    L.knncf_last_error.restype = C.c_char_p
+    L.knncf_fit.argtypes = [C.c_void_p, _i32p, _i32p, _f64p, C.c_int64]
+    L.knncf_fit_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    L.knncf_num_users.argtypes = [C.c_void_p, _i32p]
+    L.knncf_num_items.argtypes = [C.c_void_p, _i32p]
+    L.knncf_global_avg.argtypes = [C.c_void_p, _f64p]
+    for n in ("knncf_user_avg", "knncf_item_avg", "knncf_item_avg_dev"):
+        getattr(L, n).argtypes = [C.c_void_p, C.c_int32, _f64p]
+    for n in ("knncf_similarity", "knncf_knn_similarity"):
+        getattr(L, n).argtypes = [C.c_void_p, C.c_int32, C.c_int32, _f64p]
+    L.knncf_neighbors.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _i32p, _f64p, _i32p]
+    L.knncf_predict.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_int32, _f64p]
+    L.knncf_predict_batch.argtypes = [C.c_void_p, C.c_int, _i32p, _i32p, C.c_int64, _f64p]
+    L.knncf_predict_batch_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    L.knncf_mae.argtypes = [C.c_void_p, C.c_int, _i32p, _i32p, _f64p, C.c_int64, _f64p]
+    L.knncf_mae_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                   _f64p, C.POINTER(C.c_int64), C.c_void_p]
+    L.knncf_shard_view_get.argtypes = [C.c_void_p, C.POINTER(ShardView)]
+    L.knncf_shard_commit.argtypes = [C.c_void_p]
+    L.knncf_get_timings.argtypes = [C.c_void_p, C.POINTER(Timings)]
+    L.knncf_reset_timings.argtypes = [C.c_void_p]
+    L.knncf_reset_neighbors.argtypes = [C.c_void_p]
+    L.knncf_set_k.argtypes = [C.c_void_p, C.c_int32]
+    _lib = L
+    return L
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _dev_ptr(t, dtype_name):
+    """Raw device pointer of a contiguous torch tensor (torch is only plumbing for device memory)."""
+    import torch
+
+    want = {"int32": torch.int32, "float64": torch.float64}[dtype_name]
+    if not t.is_cuda or t.dtype != want or not t.is_contiguous():
+        raise ValueError(f"expected a contiguous cuda tensor of dtype {dtype_name}")
+    return C.c_void_p(t.data_ptr())
+
+
+class Engine:
+    """One knncf handle == one set of the reference's closures over a training set."""
+
+    def __init__(self, k=300, similarity=SIM_COSINE, device=0, shard_rank=0, shard_count=1,
+                 workspace_bytes=0, flags=0):
+        self._lib = load_library()
+        cfg = Config(C.sizeof(Config), device, k, similarity, shard_rank, shard_count, workspace_bytes, flags, 0)
+        h = C.c_void_p()
+        st = self._lib.knncf_create(C.byref(cfg), C.byref(h))
+        if st != OK:
+            raise KnncfError(st, self._lib.knncf_status_string(st).decode())
+        self._h = h
+        self.device = device
+        self.k = k
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.knncf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st != OK:
+            raise KnncfError(st, self._lib.knncf_last_error(self._h).decode())
+
+    # ---- fit ---------------------------------------------------------------------------
+    def fit(self, users, items, ratings):
+        u, i, r = _i32(users), _i32(items), _f64(ratings)
+        if not (len(u) == len(i) == len(r)):
+            raise ValueError("users/items/ratings differ in length")
+        self._check(self._lib.knncf_fit(self._h, u.ctypes.data_as(_i32p), i.ctypes.data_as(_i32p),
+                                        r.ctypes.data_as(_f64p), len(u)))
+        return self
+
+    def fit_device(self, users, items, ratings):
+        """users/items int32, ratings float64: contiguous torch tensors on this engine's device."""
+        n = users.numel()
+        self._check(self._lib.knncf_fit_device(self._h, _dev_ptr(users, "int32"), _dev_ptr(items, "int32"),
+                                               _dev_ptr(ratings, "float64"), n))
+        return self
+
+    @property
+    def num_users(self):
+        v = C.c_int32()
+        self._check(self._lib.knncf_num_users(self._h, C.byref(v)))
+        return v.value
+
+    @property
+    def num_items(self):
+        v = C.c_int32()
+        self._check(self._lib.knncf_num_items(self._h, C.byref(v)))
+        return v.value
+
+    # ---- scalar queries ----------------------------------------------------------------
+    def _scalar(self, fn, *args):
+        v = C.c_double()
+        self._check(fn(self._h, *args, C.byref(v)))
+        return v.value
+
+    def global_avg(self):
+        return self._scalar(self._lib.knncf_global_avg)
+
+    def user_avg(self, u):
+        return self._scalar(self._lib.knncf_user_avg, u)
+
+    def item_avg(self, i):
+        return self._scalar(self._lib.knncf_item_avg, i)
+
+    def item_avg_dev(self, i):
+        return self._scalar(self._lib.knncf_item_avg_dev, i)
+
+    def similarity(self, u, v):
+        return self._scalar(self._lib.knncf_similarity, u, v)
+
+    def knn_similarity(self, u, v):
+        return self._scalar(self._lib.knncf_knn_similarity, u, v)
+
+    def neighbors(self, u):
+        cap = max(1, self.k)
+        ids = np.empty(cap, dtype=np.int32)
+        sims = np.empty(cap, dtype=np.float64)
+        c = C.c_int32()
+        self._check(self._lib.knncf_neighbors(self._h, u, cap, ids.ctypes.data_as(_i32p),
+                                              sims.ctypes.data_as(_f64p), C.byref(c)))
+        return ids[:c.value].copy(), sims[:c.value].copy()
+
+    def predict(self, predictor, u, i):
+        return self._scalar(self._lib.knncf_predict, predictor, u, i)
+
+    # ---- batch -------------------------------------------------------------------------
+    def predict_batch(self, predictor, users, items):
+        u, i = _i32(users), _i32(items)
+        out = np.empty(len(u), dtype=np.float64)
+        self._check(self._lib.knncf_predict_batch(self._h, predictor, u.ctypes.data_as(_i32p),
+                                                  i.ctypes.data_as(_i32p), len(u), out.ctypes.data_as(_f64p)))
+        return out
+
+    def mae(self, predictor, users, items, ratings):
+        u, i, r = _i32(users), _i32(items), _f64(ratings)
+        v = C.c_double()
+        self._check(self._lib.knncf_mae(self._h, predictor, u.ctypes.data_as(_i32p), i.ctypes.data_as(_i32p),
+                                        r.ctypes.data_as(_f64p), len(u), C.byref(v)))
+        return v.value
+
+    def mae_device(self, predictor, users, items, ratings, pred_out=None):
+        """Partial (sum |r - p|, count) over the rows this shard owns; tensors on the device."""
+        s, c = C.c_double(), C.c_int64()
+        p = _dev_ptr(pred_out, "float64") if pred_out is not None else None
+        self._check(self._lib.knncf_mae_device(self._h, predictor, _dev_ptr(users, "int32"), _dev_ptr(items, "int32"),
+                                               _dev_ptr(ratings, "float64"), users.numel(), C.byref(s), C.byref(c), p))
+        return s.value, c.value
+
+    # ---- sharding ----------------------------------------------------------------------
+    def shard_view(self):
+        v = ShardView()
+        self._check(self._lib.knncf_shard_view_get(self._h, C.byref(v)))
+        return v
+
+    def shard_commit(self):
+        self._check(self._lib.knncf_shard_commit(self._h))
+
+    # ---- introspection -----------------------------------------------------------------
+    def timings(self):
+        t = Timings()
+        self._check(self._lib.knncf_get_timings(self._h, C.byref(t)))
+        return t.as_dict()
+
+    def reset_timings(self):
+        self._check(self._lib.knncf_reset_timings(self._h))
+
+    def reset_neighbors(self):
+        self._check(self._lib.knncf_reset_neighbors(self._h))
+
+    def set_k(self, k):
+        self._check(self._lib.knncf_set_k(self._h, k))
+        self.k = k

@@ -1,0 +1,135 @@
+"""GPU parity: the HIP engine (through the C ABI) against the CPU oracle on the same inputs.
+
+Bars: bit-exact neighbour ids (and, because every per-pair quantity is computed in the reference's
+order, bit-exact fp64 similarities and predictions); |dMAE| <= 1e-9 here (north_star asks 1e-6;
+only the final fixed-shape reduction differs from the reference's left fold)."""
+import importlib
+
+import numpy as np
+import pytest
+
+from tests.test_oracle_semantics import TEST, TRAIN, _cols, _no_zero_scale, _random_case
+
+pytestmark = pytest.mark.gpu
+MAE_TOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def kn(pkg):
+    mod = importlib.import_module(pkg.__name__ + ".knncf")
+    mod.load_library()
+    return mod
+
+
+def _engine(kn, train, k=300, sim=0, flags=0):
+    e = kn.Engine(k=k, similarity=sim, flags=flags)
+    e.fit(*train)
+    return e
+
+
+def test_micro_fixture(kn, oracle):
+    tr, te = _cols(TRAIN), _cols(TEST)
+    m = oracle.Model(*tr)
+    e = _engine(kn, tr, k=1)
+    assert e.num_users == 3 and e.num_items == 3
+    assert e.global_avg() == m.average()
+    assert [e.user_avg(u) for u in (1, 2, 3)] == [3.0, 3.0, 4.5]
+    assert e.user_avg(77) == m.average()
+    assert [e.item_avg_dev(i) for i in (1, 2, 3)] == [m.items_avg_dev(i) for i in (1, 2, 3)]
+    for a, b in ((1, 2), (2, 1), (1, 3), (2, 3), (1, 1)):
+        assert e.similarity(a, b) == m.fresh_similarity(0, a, b)
+    assert [e.neighbors(u)[0].tolist() for u in (1, 2, 3)] == [[2], [1], [1]]
+    assert e.mae(kn.PRED_KNN, *te) == pytest.approx(0.5, abs=1e-12)
+    np.testing.assert_array_equal(e.predict_batch(kn.PRED_KNN, te[0], te[1]), [1.0, 5.0])
+    e.set_k(2)
+    p = m.pipeline(0, 2)
+    want, preds = p.mae(*te, True)
+    np.testing.assert_array_equal(e.predict_batch(kn.PRED_KNN, te[0], te[1]), preds)
+    assert e.mae(kn.PRED_KNN, *te) == pytest.approx(want, abs=1e-15)
+    assert e.mae(kn.PRED_BASELINE, *te) == pytest.approx(0.13392857142857142, abs=1e-15)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_small_cases_bitwise(kn, oracle, seed):
+    rng = np.random.default_rng(100 + seed)
+    rows = _random_case(rng, n_users=10 + 3 * seed, n_items=17, n_ratings=80 + 11 * seed,
+                        half=(seed % 2 == 1), tiny_rows=seed % 4)
+    if not _no_zero_scale(rows):
+        pytest.skip("scale() == 0 corner")
+    cut = len(rows) * 4 // 5
+    train, test = rows[:cut], rows[cut:]
+    test += [(999_999, train[0][1], 3.0), (train[0][0], 888_888, 4.0)]
+    tr, te = _cols(train), _cols(test)
+    m = oracle.Model(*tr)
+    users = sorted(set(tr[0]))
+    items = sorted(set(tr[1]))
+    for k in (1, 4, len(users) + 3):
+        e = _engine(kn, tr, k=k, flags=kn.FLAG_VERIFY_BOUND)
+        assert e.global_avg() == m.average()
+        assert [e.user_avg(u) for u in users] == [m.users_avg(u) for u in users]
+        assert [e.item_avg(i) for i in items] == [m.items_avg(i) for i in items]
+        assert [e.item_avg_dev(i) for i in items] == [m.items_avg_dev(i) for i in items]
+        for kind, okind in ((kn.PRED_GLOBAL_AVG, 0), (kn.PRED_USER_AVG, 1), (kn.PRED_ITEM_AVG, 2),
+                            (kn.PRED_BASELINE, 3), (kn.PRED_BASELINE_RDD, 4)):
+            want, preds = m.mae(okind, *te, True)
+            np.testing.assert_array_equal(e.predict_batch(kind, te[0], te[1]), preds)
+            assert e.mae(kind, *te) == pytest.approx(want, abs=1e-13)
+        # the timed expression of predict/kNN.scala:42-45: same closure history on both sides
+        p = m.pipeline(oracle.SIM_COSINE, k)
+        want, preds = p.mae(*te, True)
+        got = e.mae(kn.PRED_KNN, *te)
+        np.testing.assert_array_equal(e.predict_batch(kn.PRED_KNN, te[0], te[1]), preds)
+        assert got == pytest.approx(want, abs=1e-13)
+        for u in users:
+            ids, sims = e.neighbors(u)
+            oids, osims = p.neighbors(u)
+            assert ids.tolist() == oids.tolist()
+            assert sims.tolist() == osims.tolist()
+            assert e.knn_similarity(u, u) == 0.0
+        assert e.timings()["max_bound_violation"] <= 0.0
+        e.close()
+    one = _engine(kn, tr, sim=kn.SIM_ONE)
+    want, preds = m.pipeline(oracle.SIM_ONE, -1).mae(*te, True)
+    np.testing.assert_array_equal(one.predict_batch(kn.PRED_PERSONALIZED, te[0], te[1]), preds)
+    jac = _engine(kn, tr, sim=kn.SIM_JACCARD)
+    for a, b in zip(users[:6], users[3:9]):
+        assert jac.similarity(a, b) == m.fresh_similarity(oracle.SIM_JACCARD, a, b)
+
+
+@pytest.mark.parametrize("shuffle", [False, True])
+def test_ml100k_shape_all_neighbours_and_predictions(kn, oracle, synth, shuffle):
+    d = synth.syn_100k(shuffle=shuffle)
+    tr = (d.train.users, d.train.items, d.train.ratings)
+    te = (d.test.users, d.test.items, d.test.ratings)
+    m = oracle.Model(*tr)
+    users = np.unique(d.train.users)
+    for k in (10, 300, 943):
+        e = _engine(kn, tr, k=k, flags=kn.FLAG_VERIFY_BOUND)
+        p = m.pipeline(oracle.SIM_COSINE, k)
+        want, preds = p.mae(*te, True)
+        got = e.mae(kn.PRED_KNN, *te)
+        gp = e.predict_batch(kn.PRED_KNN, te[0], te[1])
+        assert abs(got - want) <= MAE_TOL
+        np.testing.assert_array_equal(gp, preds)
+        for u in users[:: 7 if k != 10 else 1]:
+            ids, sims = e.neighbors(int(u))
+            oids, osims = p.neighbors(int(u))
+            assert ids.tolist() == oids.tolist(), f"user {u} k {k}"
+            assert sims.tolist() == osims.tolist()
+        t = e.timings()
+        assert t["max_bound_violation"] <= 0.0
+        assert t["gemm_launches"] >= 1
+        e.close()
+
+
+def test_fit_errors(kn):
+    e = kn.Engine(k=3)
+    with pytest.raises(kn.KnncfError) as ex:
+        e.fit([1, 1, 2], [5, 5, 5], [3.0, 4.0, 2.0])
+    assert ex.value.status == kn.E_DUPLICATE
+    with pytest.raises(kn.KnncfError) as ex:
+        e.fit([1, 1, 1], [1, 2, 3], [0.5, 1.0, 1.5])
+    assert ex.value.status == kn.E_NONFINITE
+    with pytest.raises(kn.KnncfError) as ex:
+        kn.Engine(k=3).mae(kn.PRED_KNN, [1], [1], [1.0])
+    assert ex.value.status == kn.E_STATE
