@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py — test-set predictions/s + MAE of the kNN (k=300) path on the ml-25m-shaped workload.
+
+A "step" is one pass of the reference's timed expression (predict/kNN.scala:42-45) over the
+device-resident rating triples: fit (ids, means, deviations, norms) + user x user similarity (MFMA
+GEMM) + top-k + exact re-rank + prediction of every test rating + MAE.  Inputs are synthetic (no
+MovieLens here or on the GPU box), seeded, ml-25m-shaped; they sit in HBM before the timed region.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     — the similarity GEMM (dominant kernel) against the dense bf16 MFMA peak,
+                 achieved = ALGORITHMIC flops (U (U-1) I_c) / measured kernel time
+  cpu_baseline — the fp64 CPU restatement (oracle, 1 thread like the reference's local[1]) timed on
+                 a bounded sample of the same workload on this host.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+PKG = "movie-recommender-system_amd"
+MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def make_workload(name, synth):
+    if name == "syn-25m":
+        return synth.syn_25m()
+    if name == "syn-100k":
+        return synth.syn_100k()
+    if name.startswith("syn-scaled:"):  # syn-scaled:users:items:ratings (quick rehearsals)
+        u, i, n = (int(x) for x in name.split(":")[1:4])
+        return synth.syn_scaled(u, i, n, seed=25)
+    raise SystemExit(f"unknown workload {name}")
+
+
+def cpu_baseline(split, k, budget_s, n_test_total):
+    """Oracle (C restatement, fp64, reference order, single thread) on the first test users."""
+    import numpy as np
+
+    from oracle import knncf_oracle as O
+
+    O.build()
+    tr, te = split.train, split.test
+    t0 = time.perf_counter()
+    model = O.Model(tr.users, tr.items, tr.ratings)
+    t_fit = time.perf_counter() - t0
+    pipe = model.pipeline(O.SIM_COSINE, k)
+    # first-appearance order of test users, grow the sample until the budget is spent
+    _, first = np.unique(te.users, return_index=True)
+    order = te.users[np.sort(first)]
+    done_preds, t_pred, n_users = 0, 0.0, 0
+    chunk = 4
+    while t_pred < budget_s and n_users < len(order):
+        users = order[n_users:n_users + chunk]
+        mask = np.isin(te.users, users)
+        t1 = time.perf_counter()
+        pipe.mae(te.users[mask], te.items[mask], te.ratings[mask])
+        t_pred += time.perf_counter() - t1
+        done_preds += int(mask.sum())
+        n_users += len(users)
+        chunk = min(chunk * 2, 64)
+    # whole-job rate = sample predictions / (their neighbour+predict time + their share of the fit)
+    share = t_fit * done_preds / max(1, n_test_total)
+    value = done_preds / (t_pred + share)
+    return {
+        "value": value, "unit": "predictions/s", "cores": 1, "kind": "port",
+        "sample": (f"oracle (C fp64 restatement of shared/predictions.scala, reference is single-threaded local[1]): "
+                   f"first {n_users} test users = {done_preds} predictions in {t_pred:.1f} s after a {t_fit:.1f} s fit "
+                   f"(fit amortised over all {n_test_total} predictions); host has {os.cpu_count()} cores"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="syn-25m")
+    ap.add_argument("--k", type=int, default=300)
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)  # nccl == RCCL on ROCm
+
+    importlib.import_module(PKG + ".build").build()
+    kn = importlib.import_module(PKG + ".knncf")
+    synth = importlib.import_module(PKG + ".synth")
+    sharded = importlib.import_module(PKG + ".sharded")
+
+    t0 = time.perf_counter()
+    split = make_workload(args.workload, synth)
+    tr, te = split.train, split.test
+    log(f"[rank {rank}] {split.name}: {len(tr)} train / {len(te)} test ratings generated in {time.perf_counter() - t0:.1f} s")
+    d_tr = (torch.from_numpy(tr.users).to(device), torch.from_numpy(tr.items).to(device), torch.from_numpy(tr.ratings).to(device))
+    d_te = (torch.from_numpy(te.users).to(device), torch.from_numpy(te.items).to(device), torch.from_numpy(te.ratings).to(device))
+    torch.cuda.synchronize()
+
+    eng = kn.Engine(k=args.k, similarity=kn.SIM_COSINE, device=local_rank, shard_rank=rank, shard_count=world)
+    model = sharded.ShardedKnn(sharded.DeviceEngineAdapter(eng, device), dist, rank, world)
+
+    def step():
+        model.fit(*d_tr)  # closures are rebuilt every measurement, like the reference's timed region
+        return model.mae(kn.PRED_KNN, *d_te)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    mae = float("nan")
+    for _ in range(args.warmup):
+        mae, _ = step()
+    eng.reset_timings()
+    barrier()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        mae, n_pred = step()
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    tm = eng.timings()
+
+    if rank == 0:
+        steps = max(1, args.steps)
+        n_test = len(te)
+        ms_per_step = elapsed / steps * 1e3
+        launches = max(1, tm["gemm_launches"])
+        gemm_s_per_launch = tm["gemm_ms"] / launches / 1e3
+        algo_flops_per_launch = tm["gemm_flops_algorithmic"] / launches
+        achieved = algo_flops_per_launch / gemm_s_per_launch / 1e12 if gemm_s_per_launch > 0 else 0.0
+        out = {
+            "metric": "test-set predictions/sec (kNN k=%d, fit+predict+MAE)" % args.k,
+            "value": n_test * steps / elapsed,
+            "unit": "predictions/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "bf16 similarity filter (fp32 acc) + fp64 exact re-rank/prediction",
+            "data": "synthetic",
+            "mae": mae,
+            "config": {"workload": f"{split.name}: predict.kNN k={args.k}, {eng.num_users} users x {eng.num_items} items, "
+                                   f"{len(tr)} train / {n_test} test ratings", "parallelism": f"users block-partitioned x{world}"},
+            "roofline": {
+                "bound": "mfma", "kernel": "k_gemm_nt_bf16 (user x user similarity)",
+                "achieved": achieved, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / MFMA_BF16_DENSE_PEAK_TFLOPS,
+                "executed_tflops": (tm["gemm_flops_executed"] / launches) / gemm_s_per_launch / 1e12 if gemm_s_per_launch > 0 else 0.0,
+                "launches_per_step": launches / steps, "avg_launch_ms": gemm_s_per_launch * 1e3,
+                "traffic": None,
+            },
+            "stage_ms_per_step": {k_: tm[k_] / steps for k_ in ("prep_ms", "densify_ms", "gemm_ms", "select_ms", "rerank_ms", "predict_ms")},
+            "shortlist_mean": tm["shortlist_total"] / max(1, steps * eng.num_users),
+            "fallback_rows_per_step": tm["fallback_rows"] / steps,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(split, args.k, args.cpu_baseline_seconds, n_test)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

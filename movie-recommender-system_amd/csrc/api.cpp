@@ -179,8 +179,11 @@ float gemm_eps_base() {
     return (float)(2 * u + u * u);
 }
 
+// per-row shortlist storage: rows whose error band holds more candidates than this take the exact
+// fallback.  Heavy raters have compressed similarity distributions (many candidates inside the
+// bf16 band), so the store is generous; the re-rank consumes it in LDS-sized chunks.
 int32_t shortlist_cap(int32_t k, int32_t U) {
-    int64_t want = std::max<int64_t>(2 * (int64_t)k, (int64_t)k + 1024);
+    int64_t want = std::max<int64_t>(16384, 4 * (int64_t)k);
     int64_t cap = 64;
     while (cap < want) cap <<= 1;
     int64_t upper = 64;

@@ -134,11 +134,38 @@ struct Rows {
     const double* s_pre;
 };
 
-// both rows iterate in trie order (dense item index ascending): two-pointer merge, left fold
+// lower bound of `col` in s_col[lo, hi)
+__device__ __forceinline__ int64_t lower_bound_col(const int32_t* __restrict__ s_col, int64_t lo, int64_t hi, int32_t col) {
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (s_col[mid] < col) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// both rows iterate in trie order (dense item index ascending): the common items are visited in
+// ascending order and folded left.  Rows of similar length: two-pointer merge; very different
+// lengths: walk the short row and binary-search the long one (same visiting order).
 __device__ __forceinline__ double merge_dot(const Rows& R, int32_t a, int32_t b) {
     int64_t pa = R.u_ptr[a], ea = R.u_ptr[a + 1], pb = R.u_ptr[b], eb = R.u_ptr[b + 1];
     double s = 0.0;
     if (pa >= ea || pb >= eb) return s;
+    if ((ea - pa) > 8 * (eb - pb) || (eb - pb) > 8 * (ea - pa)) {
+        if ((ea - pa) > (eb - pb)) {  // make `a` the short row (the product is commutative, the order is not affected)
+            int64_t t0 = pa; pa = pb; pb = t0;
+            t0 = ea; ea = eb; eb = t0;
+        }
+        for (; pa < ea && pb < eb; ++pa) {
+            int32_t c = R.s_col[pa];
+            pb = lower_bound_col(R.s_col, pb, eb, c);
+            if (pb < eb && R.s_col[pb] == c) {
+                s = s + R.s_pre[pa] * R.s_pre[pb];
+                ++pb;
+            }
+        }
+        return s;
+    }
     int32_t ca = R.s_col[pa], cb = R.s_col[pb];
     while (true) {
         if (ca == cb) {
@@ -206,86 +233,86 @@ __device__ __forceinline__ bool ranks_before(double sa, int32_t ia, double sb, i
     return sa > sb || (sa == sb && ia < ib);
 }
 
-// one workgroup per panel row: exact sims of the shortlist, bitonic sort, write the top kk
+// one workgroup per panel row: exact sims of the shortlist, LDS bitonic sort, keep the top kk.
+// Shortlists longer than the LDS tile are consumed in chunks: [current best kk | next chunk] is
+// sorted and cut to kk again — exact, because the comparator is a total order.
+static constexpr int RERANK_TILE = 2048;
+
 __global__ void __launch_bounds__(TPB) k_rerank(Rows R, const int64_t* __restrict__ seq, int32_t n_rows,
                                                 const int32_t* __restrict__ row_user, int32_t cap,
                                                 const int32_t* __restrict__ cand_idx, const float* __restrict__ cand_approx,
                                                 const int32_t* __restrict__ cand_cnt, int32_t kk, int32_t kcap,
                                                 int32_t* __restrict__ nbr_idx, double* __restrict__ nbr_sim,
                                                 int32_t* __restrict__ nbr_cnt, float eps_base, double* __restrict__ stats) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double ssim[RERANK_TILE];
+    __shared__ int32_t sidx[RERANK_TILE];
     const int32_t r = blockIdx.x;
     if (r >= n_rows) return;
     const int32_t cnt = cand_cnt[r];
     if (cnt > cap) return;  // overflow: the exact fallback redoes this row
     const int32_t u = row_user[r];
-    int32_t m = 1;
-    while (m < cnt) m <<= 1;
-    double* ssim = reinterpret_cast<double*>(smem);
-    int32_t* sidx = reinterpret_cast<int32_t*>(smem + (size_t)m * sizeof(double));
     const int64_t seq_u = seq[u];
     const float eps = row_eps(eps_base, R.u_ptr[u + 1] - R.u_ptr[u]);
     double worst = -1.0;
-    for (int32_t c = threadIdx.x; c < m; c += TPB) {
-        if (c < cnt) {
-            int32_t v = cand_idx[(int64_t)r * cap + c];
-            double s = pair_sim(R, u, v, seq_u, seq[v]);
-            ssim[c] = s;
-            sidx[c] = v;
-            if (cand_approx) worst = fmax(worst, fabs((double)cand_approx[(int64_t)r * cap + c] - s) - (double)eps);
-        } else {
-            ssim[c] = -INFINITY;
-            sidx[c] = 0x7fffffff;
+    int32_t best = 0, pos = 0;
+    do {
+        const int32_t take = min(RERANK_TILE - best, cnt - pos);
+        int32_t m = 1;
+        while (m < best + take) m <<= 1;
+        for (int32_t c = threadIdx.x; c < m - best; c += TPB) {
+            if (c < take) {
+                int32_t v = cand_idx[(int64_t)r * cap + pos + c];
+                double s = pair_sim(R, u, v, seq_u, seq[v]);
+                ssim[best + c] = s;
+                sidx[best + c] = v;
+                if (cand_approx) worst = fmax(worst, fabs((double)cand_approx[(int64_t)r * cap + pos + c] - s) - (double)eps);
+            } else {
+                ssim[best + c] = -INFINITY;
+                sidx[best + c] = 0x7fffffff;
+            }
         }
-    }
+        __syncthreads();
+        for (int32_t size = 2; size <= m; size <<= 1) {
+            for (int32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int32_t t = threadIdx.x; t < (m >> 1); t += TPB) {
+                    int32_t lo = 2 * t - (t & (stride - 1));
+                    int32_t hi = lo + stride;
+                    bool up = ((lo & size) == 0);  // this sub-sequence ends "best first"
+                    double sa = ssim[lo], sb = ssim[hi];
+                    int32_t ia = sidx[lo], ib = sidx[hi];
+                    bool a_first = ranks_before(sa, ia, sb, ib);
+                    if (a_first != up) {
+                        ssim[lo] = sb; ssim[hi] = sa;
+                        sidx[lo] = ib; sidx[hi] = ia;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        best = min(kk, best + take);
+        pos += take;
+    } while (pos < cnt);
     if (cand_approx && worst > -1.0) {
         // max over the grid of (|approx - exact| - eps); must stay <= 0
         unsigned long long* w = reinterpret_cast<unsigned long long*>(stats);
         double shifted = worst + 4.0;  // positive, so the bit pattern orders like the value
         atomicMax(w, (unsigned long long)__double_as_longlong(shifted));
     }
-    __syncthreads();
-    for (int32_t size = 2; size <= m; size <<= 1) {
-        for (int32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int32_t t = threadIdx.x; t < (m >> 1); t += TPB) {
-                int32_t lo = 2 * t - (t & (stride - 1));
-                int32_t hi = lo + stride;
-                bool up = ((lo & size) == 0);  // this sub-sequence ends "best first"
-                double sa = ssim[lo], sb = ssim[hi];
-                int32_t ia = sidx[lo], ib = sidx[hi];
-                bool a_first = ranks_before(sa, ia, sb, ib);
-                if (a_first != up) {
-                    ssim[lo] = sb; ssim[hi] = sa;
-                    sidx[lo] = ib; sidx[hi] = ia;
-                }
-            }
-            __syncthreads();
-        }
-    }
-    const int32_t take = kk < cnt ? kk : cnt;
-    for (int32_t j = threadIdx.x; j < take; j += TPB) {
+    for (int32_t j = threadIdx.x; j < best; j += TPB) {
         nbr_idx[(int64_t)u * kcap + j] = sidx[j];
         nbr_sim[(int64_t)u * kcap + j] = ssim[j];
     }
-    if (threadIdx.x == 0) nbr_cnt[u] = take;
+    if (threadIdx.x == 0) nbr_cnt[u] = best;
 }
 
 void launch_rerank(const Train& tr, NeighborTable& nt, int32_t n_rows, const int32_t* d_row_user, int32_t cap,
                    const int32_t* cand_idx, const float* cand_approx, const int32_t* cand_cnt, float eps,
                    double* d_stats, bool verify, hipStream_t st) {
     if (n_rows <= 0) return;
+    KN_REQUIRE(nt.kcap <= RERANK_TILE / 2, KNNCF_E_UNSUPPORTED, "k > 1024 is not supported by the re-rank kernel yet");
     Rows R{tr.u_ptr.p, tr.s_col.p, tr.s_t.p, tr.s_pre.p};
-    int32_t m = 1;
-    while (m < cap) m <<= 1;
-    size_t smem = (size_t)m * (sizeof(double) + sizeof(int32_t));
-    static size_t attr = 0;
-    if (smem > attr) {
-        KN_HIP(hipFuncSetAttribute((const void*)k_rerank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr = smem;
-    }
-    int32_t kk = nt.kcap;
-    k_rerank<<<n_rows, TPB, smem, st>>>(R, nt.seq.p, n_rows, d_row_user, cap, cand_idx, verify ? cand_approx : nullptr,
-                                        cand_cnt, kk, nt.kcap, nt.idx.p, nt.sim.p, nt.cnt.p, eps, d_stats);
+    k_rerank<<<n_rows, TPB, 0, st>>>(R, nt.seq.p, n_rows, d_row_user, cap, cand_idx, verify ? cand_approx : nullptr,
+                                     cand_cnt, nt.kcap, nt.kcap, nt.idx.p, nt.sim.p, nt.cnt.p, eps, d_stats);
     KN_HIP(hipGetLastError());
 }
 
