@@ -233,10 +233,57 @@ __device__ __forceinline__ bool ranks_before(double sa, int32_t ia, double sb, i
     return sa > sb || (sa == sb && ia < ib);
 }
 
-// one workgroup per panel row: exact sims of the shortlist, LDS bitonic sort, keep the top kk.
-// Shortlists longer than the LDS tile are consumed in chunks: [current best kk | next chunk] is
-// sorted and cut to kk again — exact, because the comparator is a total order.
+// ---- K6b kernel ----------------------------------------------------------------------------------
+// One workgroup per panel row u; u's item-sorted row is staged in LDS once.  One WAVE per candidate
+// v: the lanes stream v's row 64 entries at a time (coalesced), each lane binary-searches its item in
+// u's LDS row, and the matching products are folded left in lane (== item) order through the ballot
+// mask — the same additions in the same order as the reference's `.sum` over uItems.intersect(vItems).
+// Then an LDS bitonic sort keeps the best kk; shortlists longer than the LDS tile are consumed in
+// chunks: [current best kk | next chunk] is sorted and cut to kk again (exact: total order).
 static constexpr int RERANK_TILE = 2048;
+static constexpr int UROW_LDS = 2048;  // rows up to this many ratings are looked up in LDS, longer ones in L1/L2
+
+struct URow {
+    const int32_t* col;
+    const double* pre;
+    int32_t n;
+    int steps;  // binary-search iterations: ceil(log2(n + 1))
+};
+
+__device__ __forceinline__ double wave_merge_dot(const Rows& R, const URow& U, int32_t v, int lane) {
+    const int64_t pb = R.u_ptr[v], eb = R.u_ptr[v + 1];
+    double s = 0.0;
+    const int32_t ufirst = U.col[0], ulast = U.col[U.n - 1];
+    for (int64_t base = pb; base < eb; base += 64) {
+        const int64_t p = base + lane;
+        const bool valid = p < eb;
+        const int32_t c = valid ? R.s_col[p] : 0x7fffffff;
+        const double y = valid ? R.s_pre[p] : 0.0;
+        // the whole 64-entry piece lies outside u's item range: nothing to match
+        const int32_t cmin = __shfl(c, 0);
+        const int64_t last_valid = min(eb - 1, base + 63) - base;
+        const int32_t cmax = __shfl(c, (int)last_valid);
+        if (cmin > ulast) break;
+        if (cmax < ufirst) continue;
+        int32_t lo = 0, hi = U.n;
+        for (int it = 0; it < U.steps; ++it) {
+            int32_t mid = (lo + hi) >> 1;
+            bool go = lo < hi && U.col[min(mid, U.n - 1)] < c;
+            bool stay = lo < hi;
+            lo = go ? mid + 1 : lo;
+            hi = (stay && !go) ? mid : hi;
+        }
+        const bool match = valid && lo < U.n && U.col[lo] == c;
+        const double prod = match ? U.pre[lo] * y : 0.0;
+        unsigned long long mask = __ballot(match);
+        while (mask) {
+            int j = __ffsll((long long)mask) - 1;
+            s = s + __shfl(prod, j);
+            mask &= mask - 1;
+        }
+    }
+    return s;
+}
 
 __global__ void __launch_bounds__(TPB) k_rerank(Rows R, const int64_t* __restrict__ seq, int32_t n_rows,
                                                 const int32_t* __restrict__ row_user, int32_t cap,
@@ -246,30 +293,60 @@ __global__ void __launch_bounds__(TPB) k_rerank(Rows R, const int64_t* __restric
                                                 int32_t* __restrict__ nbr_cnt, float eps_base, double* __restrict__ stats) {
     __shared__ double ssim[RERANK_TILE];
     __shared__ int32_t sidx[RERANK_TILE];
+    __shared__ double upre[UROW_LDS];
+    __shared__ int32_t ucol[UROW_LDS];
     const int32_t r = blockIdx.x;
     if (r >= n_rows) return;
     const int32_t cnt = cand_cnt[r];
     if (cnt > cap) return;  // overflow: the exact fallback redoes this row
     const int32_t u = row_user[r];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t ub = R.u_ptr[u];
+    const int32_t nu = (int32_t)(R.u_ptr[u + 1] - ub);
+    URow U;
+    U.n = nu;
+    U.steps = 0;
+    while ((1 << U.steps) < nu + 1) ++U.steps;
+    if (nu <= UROW_LDS) {
+        for (int32_t j = threadIdx.x; j < nu; j += TPB) {
+            ucol[j] = R.s_col[ub + j];
+            upre[j] = R.s_pre[ub + j];
+        }
+        U.col = ucol;
+        U.pre = upre;
+    } else {
+        U.col = R.s_col + ub;
+        U.pre = R.s_pre + ub;
+    }
     const int64_t seq_u = seq[u];
-    const float eps = row_eps(eps_base, R.u_ptr[u + 1] - R.u_ptr[u]);
+    const float eps = row_eps(eps_base, nu);
     double worst = -1.0;
     int32_t best = 0, pos = 0;
+    __syncthreads();
     do {
         const int32_t take = min(RERANK_TILE - best, cnt - pos);
         int32_t m = 1;
         while (m < best + take) m <<= 1;
-        for (int32_t c = threadIdx.x; c < m - best; c += TPB) {
-            if (c < take) {
-                int32_t v = cand_idx[(int64_t)r * cap + pos + c];
-                double s = pair_sim(R, u, v, seq_u, seq[v]);
+        for (int32_t c = wave; c < take; c += TPB / 64) {
+            const int32_t v = cand_idx[(int64_t)r * cap + pos + c];
+            const int32_t nv = (int32_t)(R.u_ptr[v + 1] - R.u_ptr[v]);
+            double s;
+            if (nu > 4 && nv > 4) {
+                s = wave_merge_dot(R, U, v, lane);
+            } else {  // Set1..Set4 iterate in file order and the memo history matters (N2, N6): scalar path
+                s = 0.0;
+                if (lane == 0) s = pair_sim(R, u, v, seq_u, seq[v]);
+                s = __shfl(s, 0);
+            }
+            if (lane == 0) {
                 ssim[best + c] = s;
                 sidx[best + c] = v;
                 if (cand_approx) worst = fmax(worst, fabs((double)cand_approx[(int64_t)r * cap + pos + c] - s) - (double)eps);
-            } else {
-                ssim[best + c] = -INFINITY;
-                sidx[best + c] = 0x7fffffff;
             }
+        }
+        for (int32_t c = take + threadIdx.x; c < m - best; c += TPB) {
+            ssim[best + c] = -INFINITY;
+            sidx[best + c] = 0x7fffffff;
         }
         __syncthreads();
         for (int32_t size = 2; size <= m; size <<= 1) {
