@@ -182,9 +182,10 @@ def main():
                 "launches_per_step": launches / steps, "avg_launch_ms": gemm_s_per_launch * 1e3,
                 "traffic": None,
             },
-            "stage_ms_per_step": {k_: tm[k_] / steps for k_ in ("prep_ms", "densify_ms", "gemm_ms", "select_ms", "rerank_ms", "predict_ms")},
+            "stage_ms_per_step": {k_: tm[k_] / steps for k_ in ("prep_ms", "densify_ms", "gemm_ms", "tail_ms", "select_ms", "rerank_ms", "predict_ms")},
             "shortlist_mean": tm["shortlist_total"] / max(1, steps * eng.num_users),
             "fallback_rows_per_step": tm["fallback_rows"] / steps,
+            "hybrid": {"head_items": tm["head_items"], "tail_pair_updates_per_step": tm["tail_pair_updates"] / steps},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(split, args.k, args.cpu_baseline_seconds, n_test)

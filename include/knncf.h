@@ -63,14 +63,18 @@ typedef struct knncf_config {
     int32_t shard_count;     /* this handle owns block shard_rank.  1 = everything. */
     int64_t workspace_bytes; /* cap for the similarity panel + dense operand panels; 0 = auto */
     uint32_t flags;          /* KNNCF_FLAG_* */
-    uint32_t reserved;
+    uint32_t head_items;     /* hybrid similarity: the head_items most-rated items go through the dense MFMA
+                                GEMM, the sparse tail is added by fp32 atomics.  0 = cost model,
+                                KNNCF_HEAD_ALL = every item dense */
 } knncf_config;
+#define KNNCF_HEAD_ALL 0xffffffffu
 
 /* per-stage device timings of the last fit / neighbour build / predict, milliseconds */
 typedef struct knncf_timings {
     double prep_ms;     /* K0-K4: id compaction, CSR/CSC, means, deviations, norms */
     double densify_ms;  /* CSR -> bf16 panels */
     double gemm_ms;     /* K5 similarity GEMM (all launches) */
+    double tail_ms;     /* K5 sparse tail of the hybrid similarity (fp32 atomics into the panel) */
     double select_ms;   /* K6 threshold + shortlist */
     double rerank_ms;   /* K6b exact fp64 re-rank + top-k sort */
     double predict_ms;  /* K7-K9 prediction + MAE */
@@ -80,6 +84,8 @@ typedef struct knncf_timings {
     int64_t shortlist_total;       /* sum of shortlist sizes */
     int64_t fallback_rows;         /* rows re-done by the exact fallback */
     double max_bound_violation;    /* KNNCF_FLAG_VERIFY_BOUND: max(|approx-exact| - eps), <= 0 when the bound holds */
+    int64_t head_items;            /* dense head width used by the last build */
+    double tail_pair_updates;      /* sum over tail items of (raters in panel) x (raters) */
 } knncf_timings;
 
 const char* knncf_version(void);

@@ -42,6 +42,9 @@ struct knncf_handle {
     int64_t U_pad = 0, K_pad = 0;
     DArr<bf16_t> Bpanel, Apanel;
     bool b_ready = false;
+    int32_t head = 0;  // dense head width of the hybrid similarity
+    double tail_pairs_full = 0.0;
+    DArr<int32_t> colmap, row_of_user;
     DArr<float> S;
     SelectScratch sel;
     DArr<int32_t> build_list, build_count;
@@ -176,7 +179,8 @@ void reset_neighbors(knncf_handle* h) {
 // products exact in fp32, sum |x y| <= ||x|| ||y|| <= 1
 float gemm_eps_base() {
     const double u = ldexp(1.0, -8) * 1.001;
-    return (float)(2 * u + u * u);
+    // + the tail's fp32 operand/product roundings (3 * 2^-24 of sum |x y| <= 1)
+    return (float)(2 * u + u * u + 4e-7);
 }
 
 // per-row shortlist storage: rows whose error band holds more candidates than this take the exact
@@ -191,6 +195,38 @@ int32_t shortlist_cap(int32_t k, int32_t U) {
     return (int32_t)std::min(cap, upper);
 }
 
+// Width H of the dense head of the hybrid similarity.  Cost model (measured rates, MI355X): a dense
+// column costs 2 * rows * U flops on the MFMA GEMM; a tail item with c raters costs c^2 * rows / U
+// scattered fp32 atomics.  Items are in descending popularity, so the optimum is a prefix.
+int32_t choose_head(knncf_handle* h, int32_t rows_total) {
+    Train& tr = h->tr;
+    const int32_t I = tr.I;
+    const std::vector<int64_t>& c = tr.pop_count;
+    std::vector<double> tail_sq((size_t)I + 1, 0.0);
+    for (int32_t j = I - 1; j >= 0; --j) tail_sq[j] = tail_sq[j + 1] + (double)c[j] * (double)c[j];
+    int32_t H;
+    if (h->cfg.head_items == KNNCF_HEAD_ALL) {
+        H = I;
+    } else if (h->cfg.head_items > 0) {
+        H = (int32_t)std::min<int64_t>(h->cfg.head_items, I);
+    } else {
+        const double RATE_DENSE = 5.0e14;   // flop/s of k_gemm_nt_bf16 at this shape
+        const double RATE_SPARSE = 2.0e10;  // scattered fp32 atomic adds per second
+        const double frac = (double)rows_total / (double)tr.U;
+        const double U_pad = (double)round_up(tr.U, 128);
+        double best = 1e300;
+        H = I;
+        for (int64_t cand = 64;; cand += 64) {
+            int32_t hc = (int32_t)std::min<int64_t>(cand, I);
+            double cost = 2.0 * rows_total * U_pad * (double)round_up(hc, 64) / RATE_DENSE + tail_sq[hc] * frac / RATE_SPARSE;
+            if (cost < best) { best = cost; H = hc; }
+            if (hc == I) break;
+        }
+    }
+    h->tail_pairs_full = tail_sq[H];
+    return H;
+}
+
 // build the neighbourhoods of the users in h->build_list[0 .. count)
 void build_neighbors(knncf_handle* h, int32_t count) {
     Train& tr = h->tr;
@@ -200,20 +236,28 @@ void build_neighbors(knncf_handle* h, int32_t count) {
                "kNN neighbourhoods are built for the adjusted-cosine similarity only");
     hipStream_t st = h->stream;
     h->U_pad = round_up(tr.U, 128);
-    h->K_pad = round_up(tr.I, 64);
-    const int64_t U_pad = h->U_pad, K_pad = h->K_pad;
+    const int64_t U_pad = h->U_pad;
     size_t free_b = 0, total_b = 0;
     KN_HIP(hipMemGetInfo(&free_b, &total_b));
     if (!h->b_ready) {
-        size_t need = (size_t)U_pad * K_pad * sizeof(bf16_t);
+        // hybrid similarity: the H most-rated items are dense MFMA columns, the rest a sparse tail
+        h->head = choose_head(h, count);
+        h->K_pad = round_up(h->head, 64);
+        size_t need = (size_t)U_pad * h->K_pad * sizeof(bf16_t);
         KN_REQUIRE(need < free_b + h->Bpanel.bytes(), KNNCF_E_UNSUPPORTED,
-                   "dense bf16 user panel does not fit in HBM; column-panelled build is not implemented yet");
+                   "dense bf16 user panel does not fit in HBM; lower head_items");
         Stage s(h, &h->tm.densify_ms);
-        h->Bpanel.ensure((size_t)U_pad * K_pad);
-        launch_densify(tr, nullptr, 0, tr.U, nullptr, h->Bpanel.p, K_pad, U_pad, st);
+        h->colmap.ensure(tr.I);
+        launch_colmap(tr, h->head, h->colmap.p, st);
+        h->Bpanel.ensure((size_t)U_pad * h->K_pad);
+        launch_densify(tr, nullptr, 0, tr.U, h->colmap.p, h->Bpanel.p, h->K_pad, U_pad, st);
         h->b_ready = true;
         KN_HIP(hipMemGetInfo(&free_b, &total_b));
     }
+    const int64_t K_pad = h->K_pad;
+    const int32_t head = h->head;
+    h->tm.head_items = head;
+    h->row_of_user.ensure(tr.U);
     // rows per block from the similarity-panel budget
     int64_t budget = h->cfg.workspace_bytes > 0 ? h->cfg.workspace_bytes
                                                 : (int64_t)std::min<size_t>((size_t)16 << 30, (free_b + h->S.bytes() + h->Apanel.bytes()) / 3);
@@ -236,14 +280,22 @@ void build_neighbors(knncf_handle* h, int32_t count) {
         const int32_t* d_rows = h->build_list.p + rb;
         {
             Stage s(h, &h->tm.densify_ms);
-            launch_densify(tr, d_rows, 0, rows, nullptr, h->Apanel.p, K_pad, M, st);
+            launch_densify(tr, d_rows, 0, rows, h->colmap.p, h->Apanel.p, K_pad, M, st);
         }
         {
             Stage s(h, &h->tm.gemm_ms);
             launch_gemm_nt(h->Apanel.p, h->Bpanel.p, h->S.p, M, U_pad, K_pad, K_pad, K_pad, U_pad, st);
             h->tm.gemm_launches += 1;
             h->tm.gemm_flops_executed += 2.0 * (double)M * (double)U_pad * (double)K_pad;
-            h->tm.gemm_flops_algorithmic += 2.0 * (double)rows * (double)(tr.U - 1) * (double)tr.I;
+            // SURVEY 8(d) per-unit figure x the units this launch processes: ordered pairs (row, other user)
+            // x the dense columns it contracts
+            h->tm.gemm_flops_algorithmic += 2.0 * (double)rows * (double)(tr.U - 1) * (double)head;
+        }
+        if (head < tr.I) {
+            Stage s(h, &h->tm.tail_ms);
+            launch_row_of_user(tr.U, rows, d_rows, h->row_of_user.p, st);
+            launch_tail_scatter(tr, head, h->row_of_user.p, h->S.p, U_pad, st);
+            h->tm.tail_pair_updates += h->tail_pairs_full * ((double)rows / (double)tr.U);
         }
         {
             Stage s(h, &h->tm.select_ms);

@@ -49,6 +49,11 @@ struct Train {
     DArr<int64_t> i_ptr;     // [I+1]
     DArr<double> user_avg, user_norm;  // [U]
     DArr<double> item_avg, item_dev_hash, item_dev_file;  // [I]
+    // item-major copies for the sparse tail of the hybrid similarity (fp32 is enough: it only filters)
+    DArr<int32_t> it_user;   // [n] dense user of the q-th entry in (item, file) order
+    DArr<float> it_pre;      // [n] preprocessed rating of that entry
+    DArr<int32_t> pop_item;  // [I] dense items by descending number of raters
+    std::vector<int64_t> pop_count;  // host: rater counts in that order
     double global_avg = 0.0;
     int32_t own_lo = 0, own_hi = 0;  // owned dense users [lo, hi)
 };
@@ -81,6 +86,14 @@ void launch_dense_ids(const Train& tr, const int32_t* d_users, const int32_t* d_
 void launch_densify(const Train& tr, const int32_t* d_rows, int32_t row_begin, int32_t n_rows,
                     const int32_t* d_colmap, bf16_t* panel, int64_t ld, int64_t panel_rows,
                     hipStream_t st);
+// sparse tail: S[row_of_user[a]][b] += pre(a,i) * pre(b,i) for every tail item i = pop_item[first_tail + j]
+// and every pair of its raters (a in the panel, b any): fp32 atomics
+void launch_tail_scatter(const Train& tr, int32_t first_tail, const int32_t* d_row_of_user, float* S, int64_t lds,
+                         hipStream_t st);
+// colmap[item] = column of the dense head panel (popularity rank < H) or -1 (tail)
+void launch_colmap(const Train& tr, int32_t H, int32_t* d_colmap, hipStream_t st);
+// row_of_user[u] = panel row of user u or -1
+void launch_row_of_user(int32_t U, int32_t n_rows, const int32_t* d_rows, int32_t* d_row_of_user, hipStream_t st);
 // C[M][ldc] (fp32) = A[M][K] * B[N][K]^T, bf16 in / fp32 accumulate; M, N multiples of 128, K of 64
 void launch_gemm_nt(const bf16_t* A, const bf16_t* B, float* C, int64_t M, int64_t N, int64_t K,
                     int64_t lda, int64_t ldb, int64_t ldc, hipStream_t st);

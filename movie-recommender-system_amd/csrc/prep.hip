@@ -395,9 +395,41 @@ void prep_fit(Train& tr, PrepScratch& sc, int32_t shard_rank, int32_t shard_coun
                "fit: non-finite normalized deviation (a user's mean is 1 or 5 with a rating beyond it: scale() == 0)");
 }
 
+// item-major (item, file order) copies of (user, preprocessed rating) for the sparse tail
+__global__ void k_item_major(int64_t n, const uint32_t* __restrict__ perm_if, const int32_t* __restrict__ s_user,
+                             const double* __restrict__ s_pre, int32_t* __restrict__ it_user, float* __restrict__ it_pre) {
+    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    uint32_t p = perm_if[q];
+    it_user[q] = s_user[p];
+    it_pre[q] = (float)s_pre[p];
+}
+
+// key = ~count so that an ascending stable sort lists the most-rated items first (ties: dense order)
+__global__ void k_pop_keys(int32_t I, const int64_t* __restrict__ i_ptr, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
+    int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= I) return;
+    key[i] = ~(uint64_t)(i_ptr[i + 1] - i_ptr[i]);
+    val[i] = (uint32_t)i;
+}
+
 void prep_commit(Train& tr, PrepScratch& sc, hipStream_t st) {
     const int64_t n = tr.n;
     const int32_t I = tr.I;
+    // item-major copies + popularity order (hybrid similarity: dense head / sparse tail)
+    tr.it_user.alloc(n); tr.it_pre.alloc(n); tr.pop_item.alloc(I);
+    k_item_major<<<nblocks(n), TPB, 0, st>>>(n, tr.perm_if.p, tr.s_user.p, tr.s_pre.p, tr.it_user.p, tr.it_pre.p);
+    sc.k64_a.ensure(I); sc.k64_b.ensure(I); sc.v32_a.ensure(I);
+    k_pop_keys<<<nblocks(I), TPB, 0, st>>>(I, tr.i_ptr.p, sc.k64_a.p, sc.v32_a.p);
+    KN_HIP(hipGetLastError());
+    sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.v32_a.p, reinterpret_cast<uint32_t*>(tr.pop_item.p), I, 64, st);
+    {
+        std::vector<uint64_t> hk(I);
+        KN_HIP(hipMemcpyAsync(hk.data(), sc.k64_b.p, (size_t)I * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        KN_HIP(hipStreamSynchronize(st));
+        tr.pop_count.resize(I);
+        for (int32_t i = 0; i < I; ++i) tr.pop_count[i] = (int64_t)~hk[i];
+    }
     tr.item_avg.alloc(I); tr.item_dev_hash.alloc(I); tr.item_dev_file.alloc(I);
     sc.dsum.ensure((size_t)I + 2);
     // itemsAvg :134

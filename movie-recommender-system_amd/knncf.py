@@ -17,6 +17,7 @@ E_INVALID, E_NONFINITE, E_DUPLICATE, E_NOMEM, E_HIP, E_STATE, E_UNSUPPORTED, E_N
 SIM_COSINE, SIM_ONE, SIM_JACCARD = 0, 1, 2
 PRED_GLOBAL_AVG, PRED_USER_AVG, PRED_ITEM_AVG, PRED_BASELINE, PRED_BASELINE_RDD, PRED_KNN, PRED_PERSONALIZED = range(7)
 FLAG_VERIFY_BOUND = 1
+HEAD_ALL = 0xFFFFFFFF
 
 _i32p = C.POINTER(C.c_int32)
 _f64p = C.POINTER(C.c_double)
@@ -25,15 +26,16 @@ _f64p = C.POINTER(C.c_double)
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("k", C.c_int32),
                 ("similarity", C.c_int32), ("shard_rank", C.c_int32), ("shard_count", C.c_int32),
-                ("workspace_bytes", C.c_int64), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+                ("workspace_bytes", C.c_int64), ("flags", C.c_uint32), ("head_items", C.c_uint32)]
 
 
 class Timings(C.Structure):
     _fields_ = [("prep_ms", C.c_double), ("densify_ms", C.c_double), ("gemm_ms", C.c_double),
-                ("select_ms", C.c_double), ("rerank_ms", C.c_double), ("predict_ms", C.c_double),
+                ("tail_ms", C.c_double), ("select_ms", C.c_double), ("rerank_ms", C.c_double), ("predict_ms", C.c_double),
                 ("gemm_launches", C.c_int64), ("gemm_flops_executed", C.c_double),
                 ("gemm_flops_algorithmic", C.c_double), ("shortlist_total", C.c_int64),
-                ("fallback_rows", C.c_int64), ("max_bound_violation", C.c_double)]
+                ("fallback_rows", C.c_int64), ("max_bound_violation", C.c_double),
+                ("head_items", C.c_int64), ("tail_pair_updates", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -132,9 +134,10 @@ class Engine:
     """One knncf handle == one set of the reference's closures over a training set."""
 
     def __init__(self, k=300, similarity=SIM_COSINE, device=0, shard_rank=0, shard_count=1,
-                 workspace_bytes=0, flags=0):
+                 workspace_bytes=0, flags=0, head_items=0):
         self._lib = load_library()
-        cfg = Config(C.sizeof(Config), device, k, similarity, shard_rank, shard_count, workspace_bytes, flags, 0)
+        cfg = Config(C.sizeof(Config), device, k, similarity, shard_rank, shard_count, workspace_bytes, flags,
+                     head_items)
         h = C.c_void_p()
         st = self._lib.knncf_create(C.byref(cfg), C.byref(h))
         if st != OK:

@@ -21,8 +21,8 @@ def kn(pkg):
     return mod
 
 
-def _engine(kn, train, k=300, sim=0, flags=0):
-    e = kn.Engine(k=k, similarity=sim, flags=flags)
+def _engine(kn, train, k=300, sim=0, flags=0, head_items=0):
+    e = kn.Engine(k=k, similarity=sim, flags=flags, head_items=head_items)
     e.fit(*train)
     return e
 
@@ -120,6 +120,29 @@ def test_ml100k_shape_all_neighbours_and_predictions(kn, oracle, synth, shuffle)
         assert t["max_bound_violation"] <= 0.0
         assert t["gemm_launches"] >= 1
         e.close()
+
+
+@pytest.mark.parametrize("head", [64, 320, 0xFFFFFFFF])
+def test_hybrid_head_tail_split_is_exact(kn, oracle, syn100k, head):
+    """Dense MFMA head + sparse fp32-atomic tail: any split must give the same exact neighbours."""
+    d = syn100k
+    tr = (d.train.users, d.train.items, d.train.ratings)
+    te = (d.test.users, d.test.items, d.test.ratings)
+    m = oracle.Model(*tr)
+    p = m.pipeline(oracle.SIM_COSINE, 50)
+    want, preds = p.mae(*te, True)
+    e = _engine(kn, tr, k=50, flags=kn.FLAG_VERIFY_BOUND, head_items=head)
+    got = e.mae(kn.PRED_KNN, *te)
+    np.testing.assert_array_equal(e.predict_batch(kn.PRED_KNN, te[0], te[1]), preds)
+    assert abs(got - want) <= MAE_TOL
+    t = e.timings()
+    assert t["max_bound_violation"] <= 0.0
+    assert t["head_items"] == min(head, e.num_items)
+    assert (t["tail_pair_updates"] > 0) == (head < e.num_items)
+    for u in np.unique(d.train.users)[::11]:
+        ids, sims = e.neighbors(int(u))
+        oids, osims = p.neighbors(int(u))
+        assert ids.tolist() == oids.tolist() and sims.tolist() == osims.tolist()
 
 
 def test_fit_errors(kn):
