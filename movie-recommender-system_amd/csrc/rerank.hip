@@ -1,0 +1,408 @@
+// rerank.hip — K6b: exact fp64 similarities of the shortlists IN REFERENCE ORDER, and the stable
+// top-k.
+//
+// adjustedCosineSimilarityFunction shared/predictions.scala:418-426 is a left fold over
+// uItems.intersect(vItems) in the Set iteration order of the first argument (memo
+// history N6).  Dense item index == rank in that iteration order, so for users with > 4 ratings the
+// fold runs over the common items in ascending dense index.  getNeighbors :608-610 sorts
+// (allUsers - u).toSeq with sortWith(_._2 > _._2) (stable TimSort, N3) and takes k: total order
+// (similarity desc, dense user index asc).
+#include <math.h>
+#include <stdlib.h>
+
+#include "engine.h"
+
+namespace knncf {
+
+static constexpr int TPB = 256;
+
+struct Rows {
+    const int64_t* u_ptr;
+    const int32_t* s_col;
+    const uint32_t* s_t;
+    const double* s_pre;
+};
+
+// lower bound of `col` in s_col[lo, hi)
+__device__ __forceinline__ int64_t lower_bound_col(const int32_t* __restrict__ s_col, int64_t lo, int64_t hi, int32_t col) {
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (s_col[mid] < col) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// scalar path: both rows iterate in trie order (dense item index ascending): the common items are
+// visited in ascending order and folded left.  Rows of similar length: two-pointer merge; very
+// different lengths: walk the short row and binary-search the long one (same visiting order).
+__device__ __forceinline__ double merge_dot(const Rows& R, int32_t a, int32_t b) {
+    int64_t pa = R.u_ptr[a], ea = R.u_ptr[a + 1], pb = R.u_ptr[b], eb = R.u_ptr[b + 1];
+    double s = 0.0;
+    if (pa >= ea || pb >= eb) return s;
+    if ((ea - pa) > 8 * (eb - pb) || (eb - pb) > 8 * (ea - pa)) {
+        if ((ea - pa) > (eb - pb)) {  // make `a` the short row (the product is commutative, the order is not affected)
+            int64_t t0 = pa; pa = pb; pb = t0;
+            t0 = ea; ea = eb; eb = t0;
+        }
+        for (; pa < ea && pb < eb; ++pa) {
+            int32_t c = R.s_col[pa];
+            pb = lower_bound_col(R.s_col, pb, eb, c);
+            if (pb < eb && R.s_col[pb] == c) {
+                s = s + R.s_pre[pa] * R.s_pre[pb];
+                ++pb;
+            }
+        }
+        return s;
+    }
+    int32_t ca = R.s_col[pa], cb = R.s_col[pb];
+    while (true) {
+        if (ca == cb) {
+            s = s + R.s_pre[pa] * R.s_pre[pb];
+            ++pa; ++pb;
+            if (pa >= ea || pb >= eb) break;
+            ca = R.s_col[pa];
+            cb = R.s_col[pb];
+        } else if (ca < cb) {
+            if (++pa >= ea) break;
+            ca = R.s_col[pa];
+        } else {
+            if (++pb >= eb) break;
+            cb = R.s_col[pb];
+        }
+    }
+    return s;
+}
+
+__device__ __forceinline__ int64_t find_col(const Rows& R, int32_t user, int32_t col) {
+    int64_t lo = R.u_ptr[user], e = R.u_ptr[user + 1];
+    lo = lower_bound_col(R.s_col, lo, e, col);
+    return (lo < e && R.s_col[lo] == col) ? lo : -1;
+}
+
+// similarity evaluated with `w` as the first argument: an immutable.Set of <= 4 items iterates
+// in insertion (file) order, larger sets in trie order
+__device__ __forceinline__ double owner_dot(const Rows& R, int32_t w, int32_t o) {
+    int64_t b = R.u_ptr[w], n = R.u_ptr[w + 1] - b;
+    if (n > 4) return merge_dot(R, w, o);
+    // visit w's <= 4 entries by ascending file row
+    double s = 0.0;
+    uint32_t last = 0;
+    for (int64_t step = 0; step < n; ++step) {
+        int64_t best = -1;
+        uint32_t bt = 0xffffffffu;
+        for (int64_t q = 0; q < n; ++q) {
+            uint32_t t = R.s_t[b + q];
+            if ((step == 0 || t > last) && t <= bt) { bt = t; best = b + q; }
+        }
+        last = bt;
+        int64_t po = find_col(R, o, R.s_col[best]);
+        if (po >= 0) s = s + R.s_pre[best] * R.s_pre[po];
+    }
+    return s;
+}
+
+// cosine closure :415-432 as seen while building u's neighbourhood (seq_u = u's build number):
+// (v,u) is already memoised iff v's neighbourhood was built earlier, and is reused unless < 0.0
+__device__ __forceinline__ double pair_sim(const Rows& R, int32_t u, int32_t v, int64_t seq_u, int64_t seq_v) {
+    int64_t nu = R.u_ptr[u + 1] - R.u_ptr[u], nv = R.u_ptr[v + 1] - R.u_ptr[v];
+    if (nu > 4 && nv > 4) return merge_dot(R, u, v);  // same order whoever owns it
+    if (seq_v >= 0 && seq_v < seq_u) {
+        double c = owner_dot(R, v, u);
+        if (!(c < 0.0)) return c;
+    }
+    return owner_dot(R, u, v);
+}
+
+__device__ __forceinline__ bool ranks_before(double sa, int32_t ia, double sb, int32_t ib) {
+    return sa > sb || (sa == sb && ia < ib);
+}
+
+__device__ __forceinline__ float row_eps(float eps_base, int64_t row_len) {  // see select.hip
+    return eps_base + (float)row_len * 2.0f * 6.1e-8f;
+}
+
+// ---- K6b kernel ----------------------------------------------------------------------------------
+// One workgroup per panel row u.  u's item set lives in LDS as a BITMAP over the dense item index
+// plus per-word prefix popcounts, so "does u rate item c, and where" costs one LDS read (two more on a
+// hit) instead of a binary search; u's preprocessed ratings sit in LDS too (rows up to UPRE_LDS).
+// Each wave takes 64 candidates at a time: one lane per candidate fetches its row extent, then the
+// wave streams the candidates' rows as a sequence of 64-entry pieces (coalesced), always with the
+// next piece already in flight.  Matching products are compacted (ballot + popcount) into the wave's
+// LDS buffer in item order; then lane j folds candidate j's products left in fp64 — 64 independent
+// chains in parallel, each performing the same additions in the same order as the reference's `.sum`
+// over uItems.intersect(vItems).
+// Finally an LDS bitonic sort keeps the best kk; shortlists longer than the LDS tile are consumed
+// in chunks: [current best kk | next chunk] is sorted and cut to kk again (exact: total order).
+static constexpr int WBUF = 512;       // products per wave buffer
+static constexpr int UPRE_LDS = 1024;  // u's preprocessed ratings are kept in LDS up to this row length
+
+typedef const __attribute__((address_space(3))) double* lds_cf64;
+typedef __attribute__((address_space(3))) double* lds_f64;
+typedef const __attribute__((address_space(3))) uint32_t* lds_cu32;
+
+__device__ __forceinline__ void wave_sync() {
+    // lanes of one wave exchange data through LDS: order the accesses for the compiler (the LDS queue
+    // itself is in order per wave)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// exact similarities of this wave's candidates (n_c <= 64); lane j returns candidate j's
+template <class PreP>
+__device__ __forceinline__ double wave_sims(const Rows& R, lds_cu32 bits, lds_cu32 pref, PreP upre, int32_t ufirst,
+                                            int32_t ulast, lds_f64 wb, int32_t my_v, int n_c, int lane) {
+    const bool have = lane < n_c;
+    const int64_t my_b = have ? R.u_ptr[my_v] : 0;
+    const int64_t my_e = have ? R.u_ptr[my_v + 1] : 0;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    double acc = 0.0;
+    int32_t my_off = 0, my_cnt = 0, off = 0;
+    int j = 0;
+    int64_t base = __shfl(my_b, 0), eb = __shfl(my_e, 0);
+    int64_t p = base + lane;
+    int32_t c_cur = (p < eb) ? R.s_col[p] : 0x7fffffff;
+    double y_cur = (p < eb) ? R.s_pre[p] : 0.0;
+    while (j < n_c) {
+        // next piece of the stream: the same candidate's next 64 entries, or the next candidate's first
+        int nj = j;
+        int64_t nbase = base + 64, neb = eb;
+        if (nbase >= eb) {
+            nj = j + 1;
+            if (nj < n_c) {
+                nbase = __shfl(my_b, nj);
+                neb = __shfl(my_e, nj);
+            }
+        }
+        int32_t c_nxt = 0x7fffffff;
+        double y_nxt = 0.0;
+        if (nj < n_c) {
+            int64_t q = nbase + lane;
+            if (q < neb) {
+                c_nxt = R.s_col[q];
+                y_nxt = R.s_pre[q];
+            }
+        }
+        if (off + 64 > WBUF) {  // fold what has been collected; partial candidates continue in `acc`
+            wave_sync();
+            for (int32_t t = 0; t < my_cnt; ++t) acc = acc + wb[my_off + t];
+            wave_sync();
+            off = 0; my_off = 0; my_cnt = 0;
+        }
+        const int32_t cmin = __shfl(c_cur, 0);
+        const int32_t cmax = __shfl(c_cur, (int)(min(eb - 1, base + 63) - base));
+        const bool rest_empty = cmin > ulast;  // everything from here on lies beyond u's last item
+        if (!rest_empty && cmax >= ufirst) {
+            const bool valid = c_cur != 0x7fffffff;
+            const uint32_t word = valid ? bits[c_cur >> 5] : 0u;
+            const bool hit = (word >> (c_cur & 31)) & 1u;
+            const unsigned long long mask = __ballot(hit);
+            if (hit) {
+                const int32_t idx = (int32_t)pref[c_cur >> 5] + __popc(word & ((1u << (c_cur & 31)) - 1u));
+                wb[off + __popcll(mask & lt_mask)] = upre[idx] * y_cur;
+            }
+            const int32_t n = __popcll(mask);
+            if (lane == j) my_cnt += n;
+            off += n;
+        }
+        if (rest_empty && nj == j) {  // skip the candidate's remaining pieces: restart the stream at j + 1
+            nj = j + 1;
+            c_nxt = 0x7fffffff;
+            y_nxt = 0.0;
+            if (nj < n_c) {
+                nbase = __shfl(my_b, nj);
+                neb = __shfl(my_e, nj);
+                int64_t q = nbase + lane;
+                if (q < neb) {
+                    c_nxt = R.s_col[q];
+                    y_nxt = R.s_pre[q];
+                }
+            }
+        }
+        if (nj != j && lane == nj) my_off = off;  // candidate nj's products start here
+        j = nj; base = nbase; eb = neb; c_cur = c_nxt; y_cur = y_nxt;
+    }
+    wave_sync();
+    for (int32_t t = 0; t < my_cnt; ++t) acc = acc + wb[my_off + t];
+    wave_sync();
+    return acc;
+}
+
+template <int TILE>
+__global__ void __launch_bounds__(TPB) k_rerank(Rows R, const int64_t* __restrict__ seq, int32_t n_rows,
+                                                const int32_t* __restrict__ row_user, int32_t cap,
+                                                const int32_t* __restrict__ cand_idx, const float* __restrict__ cand_approx,
+                                                const int32_t* __restrict__ cand_cnt, int32_t kk, int32_t kcap,
+                                                int32_t* __restrict__ nbr_idx, double* __restrict__ nbr_sim,
+                                                int32_t* __restrict__ nbr_cnt, float eps_base, double* __restrict__ stats,
+                                                int32_t words) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ uint32_t part[TPB];
+    double* ssim = reinterpret_cast<double*>(smem);            // [TILE]
+    double* upre = ssim + TILE;                                // [UPRE_LDS]
+    double* wbuf = upre + UPRE_LDS;                            // [4][WBUF]
+    int32_t* sidx = reinterpret_cast<int32_t*>(wbuf + (TPB / 64) * WBUF);  // [TILE]
+    uint32_t* bits = reinterpret_cast<uint32_t*>(sidx + TILE);  // [words]
+    uint32_t* pref = bits + words;                              // [words]
+    const int32_t r = blockIdx.x;
+    if (r >= n_rows) return;
+    const int32_t cnt = cand_cnt[r];
+    if (cnt > cap) return;  // overflow: the exact fallback redoes this row
+    const int32_t u = row_user[r];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t ub = R.u_ptr[u];
+    const int32_t nu = (int32_t)(R.u_ptr[u + 1] - ub);
+    const bool pre_lds = nu <= UPRE_LDS;
+    // u's items as a bitmap + exclusive prefix popcounts
+    for (int32_t w = threadIdx.x; w < words; w += TPB) bits[w] = 0u;
+    __syncthreads();
+    for (int32_t j = threadIdx.x; j < nu; j += TPB) {
+        const int32_t c = R.s_col[ub + j];
+        atomicOr(&bits[c >> 5], 1u << (c & 31));
+        if (pre_lds) upre[j] = R.s_pre[ub + j];
+    }
+    __syncthreads();
+    const int32_t per = (words + TPB - 1) / TPB;
+    const int32_t w0 = min(words, (int32_t)threadIdx.x * per), w1 = min(words, w0 + per);
+    uint32_t mine = 0;
+    for (int32_t w = w0; w < w1; ++w) mine += __popc(bits[w]);
+    part[threadIdx.x] = mine;
+    __syncthreads();
+    for (int o = 1; o < TPB; o <<= 1) {  // inclusive prefix scan
+        uint32_t add = (threadIdx.x >= (unsigned)o) ? part[threadIdx.x - o] : 0;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - mine;
+    for (int32_t w = w0; w < w1; ++w) {
+        pref[w] = run;
+        run += __popc(bits[w]);
+    }
+    const int32_t ufirst = R.s_col[ub], ulast = R.s_col[ub + nu - 1];
+    const int64_t seq_u = seq[u];
+    const float eps = row_eps(eps_base, nu);
+    const int32_t* my_cand = cand_idx + (int64_t)r * cap;
+    lds_f64 wb = (lds_f64)(wbuf + wave * WBUF);
+    double worst = -1.0;
+    int32_t best = 0, pos = 0;
+    __syncthreads();
+    do {
+        const int32_t take = min(TILE - best, cnt - pos);
+        int32_t m = 1;
+        while (m < best + take) m <<= 1;
+        for (int32_t c0 = wave * 64; c0 < take; c0 += TPB) {  // 64 candidates per wave per trip
+            const int n_c = min(64, take - c0);
+            const int32_t v = (lane < n_c) ? my_cand[pos + c0 + lane] : 0;
+            double s;
+            // Set1..Set4 iterate in file order and the memo history matters (N2, N6): scalar path
+            const bool small_v = (lane < n_c) && (R.u_ptr[v + 1] - R.u_ptr[v] <= 4);
+            if (nu > 4 && !__any(small_v)) {
+                s = pre_lds ? wave_sims(R, (lds_cu32)bits, (lds_cu32)pref, (lds_cf64)upre, ufirst, ulast, wb, v, n_c, lane)
+                            : wave_sims(R, (lds_cu32)bits, (lds_cu32)pref, R.s_pre + ub, ufirst, ulast, wb, v, n_c, lane);
+            } else {
+                s = (lane < n_c) ? pair_sim(R, u, v, seq_u, seq[v]) : 0.0;
+            }
+            if (lane < n_c) {
+                ssim[best + c0 + lane] = s;
+                sidx[best + c0 + lane] = v;
+                if (cand_approx) worst = fmax(worst, fabs((double)cand_approx[(int64_t)r * cap + pos + c0 + lane] - s) - (double)eps);
+            }
+        }
+        for (int32_t c = take + threadIdx.x; c < m - best; c += TPB) {
+            ssim[best + c] = -INFINITY;
+            sidx[best + c] = 0x7fffffff;
+        }
+        __syncthreads();
+        for (int32_t size = 2; size <= m; size <<= 1) {
+            for (int32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int32_t t = threadIdx.x; t < (m >> 1); t += TPB) {
+                    int32_t lo = 2 * t - (t & (stride - 1));
+                    int32_t hi = lo + stride;
+                    bool up = ((lo & size) == 0);  // this sub-sequence ends "best first"
+                    double sa = ssim[lo], sb = ssim[hi];
+                    int32_t ia = sidx[lo], ib = sidx[hi];
+                    bool a_first = ranks_before(sa, ia, sb, ib);
+                    if (a_first != up) {
+                        ssim[lo] = sb; ssim[hi] = sa;
+                        sidx[lo] = ib; sidx[hi] = ia;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        best = min(kk, best + take);
+        pos += take;
+    } while (pos < cnt);
+    if (cand_approx) {
+        // max over the grid of (|approx - exact| - eps); must stay <= 0
+        for (int o = 32; o > 0; o >>= 1) worst = fmax(worst, __shfl_xor(worst, o));
+        if (lane == 0 && worst > -1.0) {
+            unsigned long long* w = reinterpret_cast<unsigned long long*>(stats);
+            double shifted = worst + 4.0;  // positive, so the bit pattern orders like the value
+            atomicMax(w, (unsigned long long)__double_as_longlong(shifted));
+        }
+    }
+    for (int32_t j = threadIdx.x; j < best; j += TPB) {
+        nbr_idx[(int64_t)u * kcap + j] = sidx[j];
+        nbr_sim[(int64_t)u * kcap + j] = ssim[j];
+    }
+    if (threadIdx.x == 0) nbr_cnt[u] = best;
+}
+
+template <int TILE>
+static void launch_rerank_tile(const Rows& R, const Train& tr, NeighborTable& nt, int32_t n_rows, const int32_t* d_row_user,
+                               int32_t cap, const int32_t* cand_idx, const float* cand_approx, const int32_t* cand_cnt,
+                               float eps, double* d_stats, hipStream_t st) {
+    const int32_t words = (int32_t)ceil_div(tr.I, 32);
+    const size_t smem = (size_t)TILE * 8 + (size_t)UPRE_LDS * 8 + (size_t)(TPB / 64) * WBUF * 8 + (size_t)TILE * 4 +
+                        (size_t)words * 8;
+    KN_REQUIRE(smem <= 160 * 1024 - 2048, KNNCF_E_UNSUPPORTED, "re-rank: item bitmap does not fit in LDS (too many items)");
+    static size_t attr = 0;
+    if (smem > attr) {
+        KN_HIP(hipFuncSetAttribute((const void*)k_rerank<TILE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr = smem;
+    }
+    k_rerank<TILE><<<n_rows, TPB, smem, st>>>(R, nt.seq.p, n_rows, d_row_user, cap, cand_idx, cand_approx, cand_cnt, nt.kcap,
+                                              nt.kcap, nt.idx.p, nt.sim.p, nt.cnt.p, eps, d_stats, words);
+    KN_HIP(hipGetLastError());
+}
+
+void launch_rerank(const Train& tr, NeighborTable& nt, int32_t n_rows, const int32_t* d_row_user, int32_t cap,
+                   const int32_t* cand_idx, const float* cand_approx, const int32_t* cand_cnt, float eps,
+                   double* d_stats, bool verify, hipStream_t st) {
+    if (n_rows <= 0) return;
+    KN_REQUIRE(nt.kcap <= 1024, KNNCF_E_UNSUPPORTED, "k > 1024 is not supported by the re-rank kernel yet");
+    Rows R{tr.u_ptr.p, tr.s_col.p, tr.s_t.p, tr.s_pre.p};
+    const float* apx = verify ? cand_approx : nullptr;
+    if (nt.kcap <= 512) launch_rerank_tile<1024>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, eps, d_stats, st);
+    else launch_rerank_tile<2048>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, eps, d_stats, st);
+}
+
+// exact similarities of one user against everyone (out[user] = -inf): the fallback for rows whose
+// shortlist overflowed and the engine behind scalar queries
+__global__ void k_exact_row(Rows R, const int64_t* __restrict__ seq, int32_t U, int32_t user, int64_t user_seq,
+                            double* __restrict__ out) {
+    int32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= U) return;
+    out[v] = (v == user) ? -INFINITY : pair_sim(R, user, v, user_seq, seq[v]);
+}
+
+void launch_exact_row(const Train& tr, const NeighborTable& nt, int32_t user, int64_t user_seq, double* d_out,
+                      hipStream_t st) {
+    Rows R{tr.u_ptr.p, tr.s_col.p, tr.s_t.p, tr.s_pre.p};
+    k_exact_row<<<(unsigned)ceil_div(tr.U, TPB), TPB, 0, st>>>(R, nt.seq.p, tr.U, user, user_seq, d_out);
+    KN_HIP(hipGetLastError());
+}
+
+__global__ void k_exact_pair(Rows R, int32_t u, int32_t v, double* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *out = owner_dot(R, u, v);
+}
+
+void launch_exact_pair(const Train& tr, int32_t u, int32_t v, double* d_out, hipStream_t st) {
+    Rows R{tr.u_ptr.p, tr.s_col.p, tr.s_t.p, tr.s_pre.p};
+    k_exact_pair<<<1, 64, 0, st>>>(R, u, v, d_out);
+    KN_HIP(hipGetLastError());
+}
+
+}  // namespace knncf
