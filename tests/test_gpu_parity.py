@@ -145,6 +145,100 @@ def test_hybrid_head_tail_split_is_exact(kn, oracle, syn100k, head):
         assert ids.tolist() == oids.tolist() and sims.tolist() == osims.tolist()
 
 
+def test_two_shards_on_one_gpu_equal_single_engine(kn, pkg, oracle, synth):
+    """The C-ABI shard protocol (view -> exchange -> commit -> partial MAE) with two handles in one
+    process; the exchange that RCCL's all-gather performs between GPUs is done here by device copies."""
+    import torch
+
+    sharded = importlib.import_module(pkg.__name__ + ".sharded")
+    d = synth.syn_scaled(700, 400, 42_000, seed=11, half_stars=True, shuffle=True)
+    dev = torch.device("cuda", 0)
+    tr = tuple(torch.from_numpy(a).to(dev) for a in (d.train.users, d.train.items, d.train.ratings))
+    te = tuple(torch.from_numpy(a).to(dev) for a in (d.test.users, d.test.items, d.test.ratings))
+    k = 40
+    single = kn.Engine(k=k)
+    single.fit_device(*tr)
+    s1, c1 = single.mae_device(kn.PRED_KNN, *te)
+    engines = [kn.Engine(k=k, shard_rank=r, shard_count=2) for r in range(2)]
+    views = []
+    for e in engines:
+        e.fit_device(*tr)
+        views.append(sharded.DeviceEngineAdapter(e, dev).shard_tensors())
+    assert views[0]["user_range"][1] == views[1]["user_range"][0]
+    for me, other in ((0, 1), (1, 0)):
+        ulo, uhi = views[other]["user_range"]
+        nlo, nhi = views[other]["nnz_range"]
+        for key, lo, hi in (("user_avg", ulo, uhi), ("user_norm", ulo, uhi), ("dev", nlo, nhi), ("pre", nlo, nhi)):
+            views[me][key][lo:hi] = views[other][key][lo:hi]
+    torch.cuda.synchronize()
+    total, count = 0.0, 0
+    preds = torch.zeros(len(d.test.users), dtype=torch.float64, device=dev)
+    for e in engines:
+        with pytest.raises(kn.KnncfError):  # not committed yet
+            e.mae_device(kn.PRED_KNN, *te)
+        e.shard_commit()
+        s, c = e.mae_device(kn.PRED_KNN, *te, pred_out=preds)
+        total += s
+        count += c
+    assert count == c1 == len(d.test.users)
+    assert total / count == pytest.approx(s1 / c1, abs=1e-13)
+    p = oracle.Model(d.train.users, d.train.items, d.train.ratings).pipeline(oracle.SIM_COSINE, k)
+    want, opreds = p.mae(d.test.users, d.test.items, d.test.ratings, True)
+    np.testing.assert_array_equal(preds.cpu().numpy(), opreds)
+    assert total / count == pytest.approx(want, abs=MAE_TOL)
+
+
+def test_full_size_ml25m_shape_sampled_rows_and_invariants(kn, oracle, synth):
+    """BASELINE's metric configuration (162 541 x 59 047, 20 M / 5 M ratings, k = 300): the oracle cannot
+    finish all rows in seconds, so (i) a sample of users is checked bit for bit (neighbour ids, fp64
+    similarities, predictions), (ii) size-independent properties are checked on everything."""
+    import torch
+
+    d = synth.syn_25m()
+    dev = torch.device("cuda", 0)
+    tr = tuple(torch.from_numpy(a).to(dev) for a in (d.train.users, d.train.items, d.train.ratings))
+    te = tuple(torch.from_numpy(a).to(dev) for a in (d.test.users, d.test.items, d.test.ratings))
+    e = kn.Engine(k=300)
+    e.fit_device(*tr)
+    preds = torch.zeros(len(d.test.users), dtype=torch.float64, device=dev)
+    s, c = e.mae_device(kn.PRED_KNN, *te, pred_out=preds)
+    preds = preds.cpu().numpy()
+    assert c == len(d.test.users)
+    mae = s / c
+    # (half-star data: deviations are normalised for a 1..5 scale, so a 0.5 rating can push a prediction
+    # outside [1, 5] — in the reference too; only finiteness is an invariant here)
+    assert np.all(np.isfinite(preds))
+    assert abs(mae - np.abs(d.test.ratings - preds).mean()) < 1e-9           # checksum of the per-row outputs
+    t = e.timings()
+    assert t["fallback_rows"] == 0 and t["head_items"] > 0
+    # idempotence: a second pass over the same test set (neighbourhoods already built) gives the same sums
+    s2, c2 = e.mae_device(kn.PRED_KNN, *te)
+    assert (s2, c2) == (s, c)
+    m = oracle.Model(d.train.users, d.train.items, d.train.ratings)
+    rng = np.random.default_rng(3)
+    heavy = np.argsort(np.bincount(d.train.users))[-3:]                      # the three heaviest raters too
+    sample = np.unique(np.concatenate([rng.choice(np.unique(d.test.users), 21, replace=False), heavy, [1, 2]]))
+    p = m.pipeline(oracle.SIM_COSINE, 300)
+    for u in sample:
+        ids, sims = e.neighbors(int(u))
+        oids, osims = p.neighbors(int(u))
+        assert len(ids) == 300 and int(u) not in ids.tolist()
+        assert ids.tolist() == oids.tolist(), f"user {u}"
+        assert sims.tolist() == osims.tolist()
+        assert all(sims[j] >= sims[j + 1] for j in range(299))
+    mask = np.isin(d.test.users, sample)
+    _, opreds = p.mae(d.test.users[mask], d.test.items[mask], d.test.ratings[mask], True)
+    np.testing.assert_array_equal(preds[mask], opreds)
+    assert e.global_avg() == m.average()
+    for u in sample[:5]:
+        assert e.user_avg(int(u)) == m.users_avg(int(u))
+    for i in np.unique(d.test.items)[:5]:
+        assert e.item_avg_dev(int(i)) == m.items_avg_dev(int(i))
+    want_b = m.mae(oracle.KIND_BASELINE, d.test.users, d.test.items, d.test.ratings)
+    sb, cb = e.mae_device(kn.PRED_BASELINE, *te)
+    assert sb / cb == pytest.approx(want_b, abs=MAE_TOL)
+
+
 def test_fit_errors(kn):
     e = kn.Engine(k=3)
     with pytest.raises(kn.KnncfError) as ex:
