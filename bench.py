@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--k", type=int, default=300)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--head-items", type=int, default=0, help="dense head width of the hybrid similarity (0 = cost model)")
+    ap.add_argument("--engine-flags", type=int, default=0, help="KNNCF_FLAG_* bits (1 verify bound, 2 overlap)")
     args = ap.parse_args()
 
     import numpy as np
@@ -124,7 +126,8 @@ def main():
     d_te = (torch.from_numpy(te.users).to(device), torch.from_numpy(te.items).to(device), torch.from_numpy(te.ratings).to(device))
     torch.cuda.synchronize()
 
-    eng = kn.Engine(k=args.k, similarity=kn.SIM_COSINE, device=local_rank, shard_rank=rank, shard_count=world)
+    eng = kn.Engine(k=args.k, similarity=kn.SIM_COSINE, device=local_rank, shard_rank=rank, shard_count=world,
+                    head_items=args.head_items, flags=args.engine_flags)
     model = sharded.ShardedKnn(sharded.DeviceEngineAdapter(eng, device), dist, rank, world)
 
     def step():

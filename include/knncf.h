@@ -51,6 +51,7 @@ extern "C" {
 #define KNNCF_PRED_PERSONALIZED 6 /* predictor(train, weightedSumDeviation(train, sim)) predict/Personalized.scala:61-72 */
 
 #define KNNCF_FLAG_VERIFY_BOUND 1u /* check |approx - exact| <= eps on every re-ranked pair (debug) */
+#define KNNCF_FLAG_OVERLAP 2u      /* double-buffer the row blocks: GEMM/tail of block b+1 overlap select/re-rank of block b */
 
 typedef struct knncf_handle knncf_handle;
 

@@ -118,10 +118,11 @@ struct SelectScratch {
     DArr<uint32_t> fb_vals_a, fb_vals_b;
 };
 
-// threshold + shortlist for panel rows [0, n_rows): candidates v with S[r][v] >= T_r - 2 eps
-void launch_select(const float* S, int64_t lds, int32_t n_rows, const int32_t* d_row_user,
-                   const int64_t* d_u_ptr, int32_t U, int32_t k, float eps, int32_t cap, int32_t* cand_idx,
-                   float* cand_approx, int32_t* cand_cnt, hipStream_t st);
+// per panel row: S[r][:] += sparse tail (items with colmap < 0), then threshold + shortlist:
+// candidates v with S[r][v] >= T_r - 2 eps
+void launch_tail_select(const Train& tr, const int32_t* d_colmap, bool has_tail, float* S, int64_t lds,
+                        int32_t n_rows, const int32_t* d_row_user, int32_t k, float eps, int32_t cap,
+                        int32_t* cand_idx, float* cand_approx, int32_t* cand_cnt, hipStream_t st);
 // exact fp64 similarities of the shortlists in reference order, stable top-k
 void launch_rerank(const Train& tr, NeighborTable& nt, int32_t n_rows, const int32_t* d_row_user,
                    int32_t cap, const int32_t* cand_idx, const float* cand_approx,

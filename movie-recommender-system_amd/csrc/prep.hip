@@ -405,6 +405,13 @@ __global__ void k_item_major(int64_t n, const uint32_t* __restrict__ perm_if, co
     it_pre[q] = (float)s_pre[p];
 }
 
+__global__ void k_col_keys(int64_t n, const int32_t* __restrict__ s_col, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    key[p] = (uint64_t)(uint32_t)s_col[p];
+    val[p] = (uint32_t)p;
+}
+
 // key = ~count so that an ascending stable sort lists the most-rated items first (ties: dense order)
 __global__ void k_pop_keys(int32_t I, const int64_t* __restrict__ i_ptr, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
     int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -417,9 +424,14 @@ void prep_commit(Train& tr, PrepScratch& sc, hipStream_t st) {
     const int64_t n = tr.n;
     const int32_t I = tr.I;
     // item-major copies + popularity order (hybrid similarity: dense head / sparse tail)
+    // (item, user ascending) order: a stable sort of the user-major positions by item
     tr.it_user.alloc(n); tr.it_pre.alloc(n); tr.pop_item.alloc(I);
-    k_item_major<<<nblocks(n), TPB, 0, st>>>(n, tr.perm_if.p, tr.s_user.p, tr.s_pre.p, tr.it_user.p, tr.it_pre.p);
-    sc.k64_a.ensure(I); sc.k64_b.ensure(I); sc.v32_a.ensure(I);
+    sc.k64_a.ensure(std::max<int64_t>(n, I)); sc.k64_b.ensure(std::max<int64_t>(n, I));
+    sc.v32_a.ensure(std::max<int64_t>(n, I)); sc.v32_b.ensure(n);
+    k_col_keys<<<nblocks(n), TPB, 0, st>>>(n, tr.s_col.p, sc.k64_a.p, sc.v32_a.p);
+    KN_HIP(hipGetLastError());
+    sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.v32_a.p, sc.v32_b.p, n, bits_for(I), st);
+    k_item_major<<<nblocks(n), TPB, 0, st>>>(n, sc.v32_b.p, tr.s_user.p, tr.s_pre.p, tr.it_user.p, tr.it_pre.p);
     k_pop_keys<<<nblocks(I), TPB, 0, st>>>(I, tr.i_ptr.p, sc.k64_a.p, sc.v32_a.p);
     KN_HIP(hipGetLastError());
     sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.v32_a.p, reinterpret_cast<uint32_t*>(tr.pop_item.p), I, 64, st);
