@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--head-items", type=int, default=0, help="dense head width of the hybrid similarity (0 = cost model)")
-    ap.add_argument("--engine-flags", type=int, default=0, help="KNNCF_FLAG_* bits (1 verify bound, 2 overlap)")
+    ap.add_argument("--engine-flags", type=int, default=0, help="KNNCF_FLAG_* bits (1 verify bound, 2 overlap, 4 bf16 filter operands instead of fp16)")
     args = ap.parse_args()
 
     import numpy as np
@@ -172,7 +172,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "bf16 similarity filter (fp32 acc) + fp64 exact re-rank/prediction",
+            "dtype": ("bf16" if args.engine_flags & 4 else "fp16") + " MFMA similarity filter (fp32 acc) + f64 exact re-rank/prediction",
             "data": "synthetic",
             "mae": mae,
             "config": {"workload": f"{split.name}: predict.kNN k={args.k}, {eng.num_users} users x {eng.num_items} items, "

@@ -188,10 +188,12 @@ void reset_neighbors(knncf_handle* h) {
 // per-pair error bound of the bf16 GEMM entry, excluding the per-row accumulation term that
 // select.hip adds from the row length: both operands rounded to bf16 (u = 2^-8, via fp32),
 // products exact in fp32, sum |x y| <= ||x|| ||y|| <= 1
-float gemm_eps_base() {
-    const double u = ldexp(1.0, -8) * 1.001;
+float gemm_eps_base(bool fp16) {
+    // bf16: 8 significant bits; fp16: 11 (|pre| <= 1; below 2^-14 the fp16 grid is absolute, 2^-25 per
+    // operand, folded into the constant: sum (|x| + |y|) 2^-25 <= 2 sqrt(n) 2^-25 < 6e-6 for n < 10^4)
+    const double u = ldexp(1.0, fp16 ? -11 : -8) * 1.001;
     // + the tail's fp32 operand/product roundings (3 * 2^-24 of sum |x y| <= 1)
-    return (float)(2 * u + u * u + 4e-7);
+    return (float)(2 * u + u * u + 4e-7 + (fp16 ? 6e-6 : 0.0));
 }
 
 // per-row shortlist storage: rows whose error band holds more candidates than this take the exact
@@ -221,8 +223,8 @@ int32_t choose_head(knncf_handle* h, int32_t rows_total) {
     } else if (h->cfg.head_items > 0) {
         H = (int32_t)std::min<int64_t>(h->cfg.head_items, I);
     } else {
-        const double RATE_DENSE = 5.0e14;   // flop/s of k_gemm_nt_bf16 at this shape
-        const double RATE_SPARSE = 2.0e10;  // scattered fp32 atomic adds per second
+        const double RATE_DENSE = 1.1e15;   // marginal flop/s of k_gemm_nt_bf16 per extra dense column (measured)
+        const double RATE_SPARSE = 1.2e11;  // tail pair products per second through LDS atomics (k_tail_select, measured)
         const double frac = (double)rows_total / (double)tr.U;
         const double U_pad = (double)round_up(tr.U, 128);
         double best = 1e300;
@@ -246,6 +248,7 @@ void build_neighbors(knncf_handle* h, int32_t count) {
     KN_REQUIRE(h->cfg.similarity == KNNCF_SIM_COSINE, KNNCF_E_UNSUPPORTED,
                "kNN neighbourhoods are built for the adjusted-cosine similarity only");
     hipStream_t st = h->stream;
+    const bool fp16 = (h->cfg.flags & KNNCF_FLAG_BF16_FILTER) == 0;
     h->U_pad = round_up(tr.U, 128);
     const int64_t U_pad = h->U_pad;
     size_t free_b = 0, total_b = 0;
@@ -261,7 +264,7 @@ void build_neighbors(knncf_handle* h, int32_t count) {
         h->colmap.ensure(tr.I);
         launch_colmap(tr, h->head, h->colmap.p, st);
         h->Bpanel.ensure((size_t)U_pad * h->K_pad);
-        launch_densify(tr, nullptr, 0, tr.U, h->colmap.p, h->Bpanel.p, h->K_pad, U_pad, st);
+        launch_densify(tr, nullptr, 0, tr.U, h->colmap.p, h->Bpanel.p, h->K_pad, U_pad, fp16, st);
         h->b_ready = true;
         KN_HIP(hipMemGetInfo(&free_b, &total_b));
     }
@@ -300,7 +303,7 @@ void build_neighbors(knncf_handle* h, int32_t count) {
         KN_HIP(hipHostMalloc((void**)&h->pinned_cnt, (size_t)count * sizeof(int32_t), hipHostMallocDefault));
         h->pinned_cap = (size_t)count;
     }
-    const float eps = gemm_eps_base();
+    const float eps = gemm_eps_base(fp16);
     hipStream_t sp = h->stream2;  // producer: densify, GEMM, sparse tail
     hipStream_t sc = h->stream;   // consumer: select, exact re-rank
     KN_HIP(hipEventRecord(h->ev_ready, sc));  // everything queued so far (fit, B panel) precedes the producer
@@ -314,11 +317,11 @@ void build_neighbors(knncf_handle* h, int32_t count) {
         if (b >= slots) KN_HIP(hipStreamWaitEvent(sp, h->ev_consumed[slot], 0));  // S[slot] has been read
         {
             Stage s(h, &h->tm.densify_ms, sp);
-            launch_densify(tr, d_rows, 0, rows, h->colmap.p, h->Apanel[slot].p, K_pad, M, sp);
+            launch_densify(tr, d_rows, 0, rows, h->colmap.p, h->Apanel[slot].p, K_pad, M, fp16, sp);
         }
         {
             Stage s(h, &h->tm.gemm_ms, sp);
-            launch_gemm_nt(h->Apanel[slot].p, h->Bpanel.p, h->S[slot].p, M, U_pad, K_pad, K_pad, K_pad, U_pad, sp);
+            launch_gemm_nt(h->Apanel[slot].p, h->Bpanel.p, h->S[slot].p, M, U_pad, K_pad, K_pad, K_pad, U_pad, fp16, sp);
             h->tm.gemm_launches += 1;
             h->tm.gemm_flops_executed += 2.0 * (double)M * (double)U_pad * (double)K_pad;
             // SURVEY 8(d) per-unit figure x the units this launch processes: ordered pairs (row, other user)

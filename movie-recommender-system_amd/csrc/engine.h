@@ -84,7 +84,7 @@ void launch_dense_ids(const Train& tr, const int32_t* d_users, const int32_t* d_
 // ---- gemm.hip: densify + K5 ------------------------------------------------------------
 // rows[r] = dense user of panel row r (nullptr: panel row r == user row_begin + r)
 void launch_densify(const Train& tr, const int32_t* d_rows, int32_t row_begin, int32_t n_rows,
-                    const int32_t* d_colmap, bf16_t* panel, int64_t ld, int64_t panel_rows,
+                    const int32_t* d_colmap, bf16_t* panel, int64_t ld, int64_t panel_rows, bool fp16,
                     hipStream_t st);
 // sparse tail: S[row_of_user[a]][b] += pre(a,i) * pre(b,i) for every tail item i = pop_item[first_tail + j]
 // and every pair of its raters (a in the panel, b any): fp32 atomics
@@ -96,7 +96,7 @@ void launch_colmap(const Train& tr, int32_t H, int32_t* d_colmap, hipStream_t st
 void launch_row_of_user(int32_t U, int32_t n_rows, const int32_t* d_rows, int32_t* d_row_of_user, hipStream_t st);
 // C[M][ldc] (fp32) = A[M][K] * B[N][K]^T, bf16 in / fp32 accumulate; M, N multiples of 128, K of 64
 void launch_gemm_nt(const bf16_t* A, const bf16_t* B, float* C, int64_t M, int64_t N, int64_t K,
-                    int64_t lda, int64_t ldb, int64_t ldc, hipStream_t st);
+                    int64_t lda, int64_t ldb, int64_t ldc, bool fp16, hipStream_t st);
 
 // ---- select.hip: K6 + K6b --------------------------------------------------------------
 struct NeighborTable {

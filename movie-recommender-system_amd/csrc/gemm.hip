@@ -18,9 +18,11 @@
 namespace knncf {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 // ---- densify -----------------------------------------------------------------------------
+template <bool F16>
 __global__ void k_densify(const int64_t* __restrict__ u_ptr, const int32_t* __restrict__ s_col,
                           const double* __restrict__ s_pre, const int32_t* __restrict__ rows, int32_t row_begin,
                           int32_t n_rows, const int32_t* __restrict__ colmap, bf16_t* __restrict__ panel, int64_t ld) {
@@ -33,16 +35,20 @@ __global__ void k_densify(const int64_t* __restrict__ u_ptr, const int32_t* __re
     bf16_t* out = panel + (int64_t)wave * ld;
     for (int64_t p = b + lane; p < e; p += 64) {
         int32_t c = colmap ? colmap[s_col[p]] : s_col[p];
-        if (c >= 0) out[c] = (bf16_t)(float)s_pre[p];
+        if (c >= 0) {
+            if (F16) reinterpret_cast<_Float16*>(out)[c] = (_Float16)(float)s_pre[p];
+            else out[c] = (bf16_t)(float)s_pre[p];
+        }
     }
 }
 
 void launch_densify(const Train& tr, const int32_t* d_rows, int32_t row_begin, int32_t n_rows,
-                    const int32_t* d_colmap, bf16_t* panel, int64_t ld, int64_t panel_rows, hipStream_t st) {
+                    const int32_t* d_colmap, bf16_t* panel, int64_t ld, int64_t panel_rows, bool fp16, hipStream_t st) {
     KN_HIP(hipMemsetAsync(panel, 0, (size_t)panel_rows * ld * sizeof(bf16_t), st));
     if (n_rows <= 0) return;
     int blocks = (int)ceil_div((int64_t)n_rows * 64, 256);
-    k_densify<<<blocks, 256, 0, st>>>(tr.u_ptr.p, tr.s_col.p, tr.s_pre.p, d_rows, row_begin, n_rows, d_colmap, panel, ld);
+    if (fp16) k_densify<true><<<blocks, 256, 0, st>>>(tr.u_ptr.p, tr.s_col.p, tr.s_pre.p, d_rows, row_begin, n_rows, d_colmap, panel, ld);
+    else k_densify<false><<<blocks, 256, 0, st>>>(tr.u_ptr.p, tr.s_col.p, tr.s_pre.p, d_rows, row_begin, n_rows, d_colmap, panel, ld);
     KN_HIP(hipGetLastError());
 }
 
@@ -143,6 +149,7 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int row, int c
     return *reinterpret_cast<const bf16x8*>(lds_tile + row * 128 + slot * 16);
 }
 
+template <bool F16>
 __global__ void __launch_bounds__(256, 2)
 k_gemm_nt_bf16(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, float* __restrict__ C, int tiles_m,
                int tiles_n, int k_tiles, int64_t lda, int64_t ldb, int64_t ldc) {
@@ -203,10 +210,17 @@ k_gemm_nt_bf16(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, float
             bf16x8 a1 = read_frag(cur, wr * 64 + 32 + frow, ks * 2 + fhalf);
             bf16x8 b0 = read_frag(cur + TILE_BYTES, wc * 64 + frow, ks * 2 + fhalf);
             bf16x8 b1 = read_frag(cur + TILE_BYTES, wc * 64 + 32 + frow, ks * 2 + fhalf);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            if (F16) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, b0), acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, b1), acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1), __builtin_bit_cast(f16x8, b0), acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1), __builtin_bit_cast(f16x8, b1), acc[1][1], 0, 0, 0);
+            } else {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // everyone is done reading `cur` before it is restaged
@@ -228,17 +242,19 @@ k_gemm_nt_bf16(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, float
 }
 
 void launch_gemm_nt(const bf16_t* A, const bf16_t* B, float* C, int64_t M, int64_t N, int64_t K, int64_t lda,
-                    int64_t ldb, int64_t ldc, hipStream_t st) {
+                    int64_t ldb, int64_t ldc, bool fp16, hipStream_t st) {
     KN_REQUIRE(M % BM == 0 && N % BN == 0 && K % BK == 0 && K > 0, KNNCF_E_INVALID, "gemm: shape not tile-aligned");
     KN_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, KNNCF_E_INVALID, "gemm: leading dimensions must be multiples of 8");
     int64_t tiles = (M / BM) * (N / BN);
     KN_REQUIRE(tiles > 0 && tiles < (1ll << 31), KNNCF_E_INVALID, "gemm: grid too large");
     static bool attr_set = false;
     if (!attr_set) {
-        KN_HIP(hipFuncSetAttribute((const void*)k_gemm_nt_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES));
+        KN_HIP(hipFuncSetAttribute((const void*)k_gemm_nt_bf16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES));
+        KN_HIP(hipFuncSetAttribute((const void*)k_gemm_nt_bf16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES));
         attr_set = true;
     }
-    k_gemm_nt_bf16<<<(unsigned)tiles, 256, 2 * STAGE_BYTES, st>>>(A, B, C, (int)(M / BM), (int)(N / BN), (int)(K / BK), lda, ldb, ldc);
+    if (fp16) k_gemm_nt_bf16<true><<<(unsigned)tiles, 256, 2 * STAGE_BYTES, st>>>(A, B, C, (int)(M / BM), (int)(N / BN), (int)(K / BK), lda, ldb, ldc);
+    else k_gemm_nt_bf16<false><<<(unsigned)tiles, 256, 2 * STAGE_BYTES, st>>>(A, B, C, (int)(M / BM), (int)(N / BN), (int)(K / BK), lda, ldb, ldc);
     KN_HIP(hipGetLastError());
 }
 

@@ -17,6 +17,8 @@ E_INVALID, E_NONFINITE, E_DUPLICATE, E_NOMEM, E_HIP, E_STATE, E_UNSUPPORTED, E_N
 SIM_COSINE, SIM_ONE, SIM_JACCARD = 0, 1, 2
 PRED_GLOBAL_AVG, PRED_USER_AVG, PRED_ITEM_AVG, PRED_BASELINE, PRED_BASELINE_RDD, PRED_KNN, PRED_PERSONALIZED = range(7)
 FLAG_VERIFY_BOUND = 1
+FLAG_OVERLAP = 2
+FLAG_BF16_FILTER = 4  # default filter operand type is fp16 (narrower error band, same MFMA rate)
 HEAD_ALL = 0xFFFFFFFF
 
 _i32p = C.POINTER(C.c_int32)

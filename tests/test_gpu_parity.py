@@ -122,16 +122,18 @@ def test_ml100k_shape_all_neighbours_and_predictions(kn, oracle, synth, shuffle)
         e.close()
 
 
+@pytest.mark.parametrize("bf16", [False, True])
 @pytest.mark.parametrize("head", [64, 320, 0xFFFFFFFF])
-def test_hybrid_head_tail_split_is_exact(kn, oracle, syn100k, head):
-    """Dense MFMA head + sparse fp32-atomic tail: any split must give the same exact neighbours."""
+def test_hybrid_head_tail_split_is_exact(kn, oracle, syn100k, head, bf16):
+    """Dense MFMA head (fp16 or bf16 operands) + sparse fp32 LDS-atomic tail: any split and either
+    filter precision must give the same exact neighbours, inside the rigorous error band."""
     d = syn100k
     tr = (d.train.users, d.train.items, d.train.ratings)
     te = (d.test.users, d.test.items, d.test.ratings)
     m = oracle.Model(*tr)
     p = m.pipeline(oracle.SIM_COSINE, 50)
     want, preds = p.mae(*te, True)
-    e = _engine(kn, tr, k=50, flags=kn.FLAG_VERIFY_BOUND, head_items=head)
+    e = _engine(kn, tr, k=50, flags=kn.FLAG_VERIFY_BOUND | (kn.FLAG_BF16_FILTER if bf16 else 0), head_items=head)
     got = e.mae(kn.PRED_KNN, *te)
     np.testing.assert_array_equal(e.predict_batch(kn.PRED_KNN, te[0], te[1]), preds)
     assert abs(got - want) <= MAE_TOL
