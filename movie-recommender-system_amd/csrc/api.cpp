@@ -293,7 +293,7 @@ void build_neighbors(knncf_handle* h, int32_t count) {
     const int32_t cap = shortlist_cap(nt.k, tr.U);
     const bool verify = (h->cfg.flags & KNNCF_FLAG_VERIFY_BOUND) != 0;
     h->sel.cand_idx.ensure((size_t)R * cap);
-    if (verify) h->sel.cand_approx.ensure((size_t)R * cap);
+    h->sel.cand_approx.ensure((size_t)R * cap);
     h->sel.cand_cnt.ensure(R);
     h->sel.stats.ensure(4);
     if (h->pinned_cap < (size_t)count) {
@@ -334,7 +334,7 @@ void build_neighbors(knncf_handle* h, int32_t count) {
             // sparse tail (LDS atomics per row tile) + histogram select, fused: one pass over S
             Stage s(h, &h->tm.select_ms, sc);
             launch_tail_select(tr, h->colmap.p, head < tr.I, h->S[slot].p, U_pad, rows, d_rows, nt.k, eps, cap,
-                               h->sel.cand_idx.p, verify ? h->sel.cand_approx.p : nullptr, h->sel.cand_cnt.p, sc);
+                               h->sel.cand_idx.p, h->sel.cand_approx.p, h->sel.cand_cnt.p, sc);
             h->tm.tail_pair_updates += h->tail_pairs_full * ((double)rows / (double)tr.U);
         }
         if (overlap) KN_HIP(hipEventRecord(h->ev_consumed[slot], sc));

@@ -1,19 +1,21 @@
 // select.hip — K5 sparse tail + K6 top-k neighbour select, fused per similarity row.
 //
 // The dense MFMA GEMM (gemm.hip) leaves S[u][v] = sum over the H most-rated items.  For row u this
-// kernel (one 1024-thread workgroup per row)
-//   1. adds the SPARSE TAIL: for every tail item i rated by u and every rater v of i,
-//      pre(u,i) * pre(v,i) is accumulated with LDS float atomics into a column tile of the row
-//      (24 576 columns = 96 KiB of LDS at a time; the rater lists are sorted by user, so each list is
-//      swept once across the tiles with a per-entry cursor kept in LDS); the tile is added to S and
-//      written back (coalesced);
-//   2. builds a 4096-bin LDS histogram of the final row in the same pass and finds the bin holding
-//      the k-th largest value a_k by a block-wide suffix scan;
-//   3. compacts every v with S[u][v] >= (bin lower edge) - 2 eps into the row's shortlist.
+// kernel (one 1024-thread workgroup per row) walks the row ONCE, a column tile (20 480 columns =
+// 80 KiB of LDS) at a time:
+//   1. SPARSE TAIL: for every tail item i rated by u and every rater v of i inside the tile,
+//      pre(u,i) * pre(v,i) is accumulated with LDS float atomics (the rater lists are sorted by user,
+//      so each list is swept once across the tiles with a per-entry cursor kept in LDS);
+//   2. the tile's final values S + tail stay in LDS and enter a cumulative 4096-bin histogram; the
+//      bin holding the k-th largest value SEEN SO FAR gives a threshold that can only rise as more
+//      columns are seen, so every v of the tile with value >= (bin lower edge - 2 eps) is appended to
+//      a provisional shortlist straight from LDS;
+//   3. after the last tile the threshold is final and the provisional list is compacted in place.
 // With |S[u][v] - s_uv| <= eps for every pair, every true top-k member v satisfies
-// S[u][v] >= a_k - 2 eps, so the shortlist provably contains the exact top-k; rerank.hip decides.
-// HBM-bound: S is read + written once and re-read once (second pass mostly L2/MALL); the tail's
-// per-pair products never touch HBM atomics.
+// S[u][v] >= a_k - 2 eps (a_k = k-th largest value of the row), so the shortlist provably contains
+// the exact top-k; rerank.hip decides.  HBM-bound: S is read exactly once and never written back
+// (rows with > EMAX ratings take extra read-modify-write sweeps); the tail's per-pair products never
+// touch HBM atomics.
 #include <math.h>
 
 #include "engine.h"
@@ -24,6 +26,7 @@ static constexpr int TPB = 1024;
 static constexpr int NBINS = 4096;
 static constexpr int TCOLS = 20480;  // columns of the row held in LDS at a time (80 KiB)
 static constexpr int EMAX = 2048;    // row positions whose tail cursors are held in LDS at a time
+static constexpr int MAX_PER_THREAD = 16;  // provisional entries per thread in the final compaction
 
 __device__ __forceinline__ int sim_bin(float x) {
     int b = (int)floorf((x + 1.0f) * (NBINS / 2));
@@ -47,6 +50,47 @@ struct TailArgs {
     int32_t has_tail;
 };
 
+// threshold from the cumulative histogram: lower edge of the bin holding the kk-th largest value seen so
+// far, minus 2 eps (-inf while fewer than kk values have been seen).  Thread t owns bins [4t, 4t+4).
+__device__ __forceinline__ void block_threshold(const uint32_t* hist, uint32_t* wtot, float* s_thr, int32_t kk, float eps) {
+    constexpr int PER = NBINS / TPB;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t h[PER];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        h[j] = hist[threadIdx.x * PER + j];
+        mine += h[j];
+    }
+    // inclusive suffix sum inside the wave (lanes above me + me)
+    uint32_t suf = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t up = __shfl_down(suf, o);
+        if (lane + o < 64) suf += up;
+    }
+    if (lane == 0) wtot[wave] = suf;
+    if (threadIdx.x == 0) *s_thr = -INFINITY;
+    __syncthreads();
+    uint32_t higher = 0;  // values in the waves above mine
+    for (int w = wave + 1; w < TPB / 64; ++w) higher += wtot[w];
+    const uint32_t incl = suf + higher;        // values in my bins and above
+    const uint32_t above = incl - mine;        // values strictly above my bins
+    if (above < (uint32_t)kk && incl >= (uint32_t)kk) {
+        uint32_t c = above;
+        int j = PER - 1;
+        for (; j > 0; --j) {
+            c += h[j];
+            if (c >= (uint32_t)kk) break;
+        }
+        const int b = threadIdx.x * PER + j;
+        // every value in bin b is >= its lower edge (up to one float rounding of x + 1)
+        const float edge = (float)b / (float)(NBINS / 2) - 1.0f;
+        *s_thr = (b == 0) ? -INFINITY : edge - 2.0f * eps - 1e-6f;
+    }
+    __syncthreads();
+}
+
 __global__ void __launch_bounds__(TPB) k_tail_select(float* __restrict__ S, int64_t ld, int32_t n_rows,
                                                      const int32_t* __restrict__ row_user, TailArgs T, int32_t U,
                                                      int32_t kk, float eps_base, int32_t cap, int32_t* __restrict__ cand_idx,
@@ -57,7 +101,7 @@ __global__ void __launch_bounds__(TPB) k_tail_select(float* __restrict__ S, int6
     int64_t* e_cur = reinterpret_cast<int64_t*>(hist + NBINS);    // [EMAX] cursor into it_user / it_pre
     int64_t* e_end = e_cur + EMAX;                                // [EMAX]
     float* e_x = reinterpret_cast<float*>(e_end + EMAX);          // [EMAX] pre(u, item)
-    __shared__ uint32_t part[TPB];
+    __shared__ uint32_t wtot[TPB / 64];
     __shared__ float s_thr;
     __shared__ uint32_t s_count;
     __shared__ int32_t s_ne;
@@ -68,12 +112,13 @@ __global__ void __launch_bounds__(TPB) k_tail_select(float* __restrict__ S, int6
     const int64_t ub = T.u_ptr[u], ue = T.u_ptr[u + 1];
     const float eps = row_eps(eps_base, ue - ub);
     float* row = S + (int64_t)r * ld;
+    int32_t* out_idx = cand_idx + (int64_t)r * cap;
+    float* out_apx = cand_approx + (int64_t)r * cap;
     for (int b = threadIdx.x; b < NBINS; b += TPB) hist[b] = 0;
     if (threadIdx.x == 0) s_count = 0;
 
-    // ---- pass 1: tail accumulation (LDS), write-back, histogram --------------------------------
-    // the row is taken EMAX positions at a time (one chunk for all but the heaviest raters); every
-    // chunk sweeps the column tiles once, the last one also histograms the final values
+    // the row is taken EMAX positions at a time (one chunk for all but the heaviest raters); every chunk
+    // sweeps the column tiles once; the last one selects, earlier ones only add their tail part to S
     int64_t cb = ub;
     bool last_chunk;
     do {
@@ -122,93 +167,80 @@ __global__ void __launch_bounds__(TPB) k_tail_select(float* __restrict__ S, int6
                 }
                 __syncthreads();
             }
-            if (ne > 0 || last_chunk) {
-                // S += tile (if something was accumulated); histogram of the final values on the last chunk
-                for (int32_t c = threadIdx.x * 4; c < t1 - t0; c += TPB * 4) {
-                    const int32_t v0 = t0 + c;
-                    if (v0 + 3 < t1) {
-                        float4 x = *reinterpret_cast<const float4*>(row + v0);
-                        if (ne > 0) {
-                            x.x += tile[c]; x.y += tile[c + 1]; x.z += tile[c + 2]; x.w += tile[c + 3];
-                            *reinterpret_cast<float4*>(row + v0) = x;
-                        }
-                        if (last_chunk) {
-                            if (v0 + 0 != u) atomicAdd(&hist[sim_bin(x.x)], 1u);
-                            if (v0 + 1 != u) atomicAdd(&hist[sim_bin(x.y)], 1u);
-                            if (v0 + 2 != u) atomicAdd(&hist[sim_bin(x.z)], 1u);
-                            if (v0 + 3 != u) atomicAdd(&hist[sim_bin(x.w)], 1u);
-                        }
-                    } else {
-                        for (int32_t v = v0; v < t1; ++v) {
-                            float x = row[v];
-                            if (ne > 0) {
-                                x += tile[v - t0];
-                                row[v] = x;
-                            }
-                            if (last_chunk && v != u) atomicAdd(&hist[sim_bin(x)], 1u);
-                        }
+            if (!last_chunk) {
+                if (ne > 0) {  // S += this chunk's tail part
+                    for (int32_t c = threadIdx.x; c < t1 - t0; c += TPB) row[t0 + c] += tile[c];
+                    __syncthreads();
+                }
+                continue;
+            }
+            // final values of the tile -> LDS, cumulative histogram
+            for (int32_t c = threadIdx.x * 4; c < t1 - t0; c += TPB * 4) {
+                const int32_t v0 = t0 + c;
+                if (v0 + 3 < t1) {
+                    float4 x = *reinterpret_cast<const float4*>(row + v0);
+                    if (ne > 0) { x.x += tile[c]; x.y += tile[c + 1]; x.z += tile[c + 2]; x.w += tile[c + 3]; }
+                    tile[c] = x.x; tile[c + 1] = x.y; tile[c + 2] = x.z; tile[c + 3] = x.w;
+                    if (v0 + 0 != u) atomicAdd(&hist[sim_bin(x.x)], 1u);
+                    if (v0 + 1 != u) atomicAdd(&hist[sim_bin(x.y)], 1u);
+                    if (v0 + 2 != u) atomicAdd(&hist[sim_bin(x.z)], 1u);
+                    if (v0 + 3 != u) atomicAdd(&hist[sim_bin(x.w)], 1u);
+                } else {
+                    for (int32_t v = v0; v < t1; ++v) {
+                        float x = row[v];
+                        if (ne > 0) x += tile[v - t0];
+                        tile[v - t0] = x;
+                        if (v != u) atomicAdd(&hist[sim_bin(x)], 1u);
                     }
                 }
-                __syncthreads();
             }
+            __syncthreads();
+            block_threshold(hist, wtot, &s_thr, kk, eps);
+            const float thr = s_thr;  // valid for every column seen so far; it can only rise later
+            for (int32_t c = threadIdx.x; c < t1 - t0; c += TPB) {
+                const float x = tile[c];
+                const int32_t v = t0 + c;
+                if (v != u && x >= thr) {
+                    const uint32_t pos = atomicAdd(&s_count, 1u);
+                    if (pos < (uint32_t)cap) {
+                        out_idx[pos] = v;
+                        out_apx[pos] = x;
+                    }
+                }
+            }
+            __syncthreads();
         }
         cb = ce;
     } while (!last_chunk);
 
-    // ---- k-th bin: suffix counts, thread t owns bins [4 t, 4 t + 4) --------------------------------
-    constexpr int PER = NBINS / TPB;
-    uint32_t mine = 0;
-    for (int j = 0; j < PER; ++j) mine += hist[threadIdx.x * PER + j];
-    part[threadIdx.x] = mine;
-    __syncthreads();
-    for (int o = 1; o < TPB; o <<= 1) {  // inclusive suffix scan
-        uint32_t add = (threadIdx.x + o < TPB) ? part[threadIdx.x + o] : 0;
-        __syncthreads();
-        part[threadIdx.x] += add;
-        __syncthreads();
+    // ---- compaction of the provisional list by the final threshold (in place) ------------------------
+    const uint32_t prov = s_count;
+    if (prov > (uint32_t)cap) {  // provisional overflow: the exact fallback redoes this row
+        if (threadIdx.x == 0) cand_cnt[r] = (int32_t)min(prov, (uint32_t)0x7fffffff);
+        return;
     }
-    uint32_t above = (threadIdx.x + 1 < TPB) ? part[threadIdx.x + 1] : 0;  // count in higher bins
-    if (above < (uint32_t)kk && part[threadIdx.x] >= (uint32_t)kk) {
-        uint32_t c = above;
-        int b = threadIdx.x * PER + PER - 1;
-        for (; b > (int)threadIdx.x * PER; --b) {
-            c += hist[b];
-            if (c >= (uint32_t)kk) break;
-        }
-        // every value in bin b is >= its lower edge (up to one float rounding of x + 1)
-        float edge = (float)b / (float)(NBINS / 2) - 1.0f;
-        s_thr = (b == 0) ? -INFINITY : edge - 2.0f * eps - 1e-6f;
-    }
-    __syncthreads();
-
-    // ---- pass 2: compaction of the error band ---------------------------------------------------
     const float thr = s_thr;
-    int32_t* out_idx = cand_idx + (int64_t)r * cap;
-    float* out_apx = cand_approx ? cand_approx + (int64_t)r * cap : nullptr;
-    const int32_t U4 = U & ~3;
-    for (int32_t v0 = threadIdx.x * 4; v0 < U4; v0 += TPB * 4) {
-        float4 x4 = *reinterpret_cast<const float4*>(row + v0);
-        float xs[4] = {x4.x, x4.y, x4.z, x4.w};
+    int32_t kv[MAX_PER_THREAD];
+    float kx[MAX_PER_THREAD];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int32_t v = v0 + j;
-            if (v != u && xs[j] >= thr) {
-                uint32_t pos = atomicAdd(&s_count, 1u);
-                if (pos < (uint32_t)cap) {
-                    out_idx[pos] = v;
-                    if (out_apx) out_apx[pos] = xs[j];
-                }
-            }
+    for (int j = 0; j < MAX_PER_THREAD; ++j) {
+        const uint32_t i = threadIdx.x + (uint32_t)j * TPB;
+        kv[j] = -1;
+        kx[j] = 0.f;
+        if (i < prov) {
+            kv[j] = out_idx[i];
+            kx[j] = out_apx[i];
         }
     }
-    for (int32_t v = U4 + threadIdx.x; v < U; v += TPB) {
-        float x = row[v];
-        if (v != u && x >= thr) {
-            uint32_t pos = atomicAdd(&s_count, 1u);
-            if (pos < (uint32_t)cap) {
-                out_idx[pos] = v;
-                if (out_apx) out_apx[pos] = x;
-            }
+    __syncthreads();
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < MAX_PER_THREAD; ++j) {
+        if (kv[j] >= 0 && kx[j] >= thr) {
+            const uint32_t pos = atomicAdd(&s_count, 1u);
+            out_idx[pos] = kv[j];
+            out_apx[pos] = kx[j];
         }
     }
     __syncthreads();
@@ -219,6 +251,7 @@ void launch_tail_select(const Train& tr, const int32_t* d_colmap, bool has_tail,
                         int32_t n_rows, const int32_t* d_row_user, int32_t k, float eps, int32_t cap,
                         int32_t* cand_idx, float* cand_approx, int32_t* cand_cnt, hipStream_t st) {
     if (n_rows <= 0) return;
+    KN_REQUIRE(cap <= TPB * MAX_PER_THREAD, KNNCF_E_INVALID, "select: shortlist store larger than the compaction window");
     const int32_t U = tr.U;
     int32_t kk = k < U - 1 ? k : U - 1;
     if (kk < 1) kk = 1;
