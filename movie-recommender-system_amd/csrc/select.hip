@@ -17,6 +17,7 @@
 // (rows with > EMAX ratings take extra read-modify-write sweeps); the tail's per-pair products never
 // touch HBM atomics.
 #include <math.h>
+#include <stdlib.h>
 
 #include "engine.h"
 
@@ -27,6 +28,13 @@ static constexpr int NBINS = 4096;
 static constexpr int TCOLS = 20480;  // columns of the row held in LDS at a time (80 KiB)
 static constexpr int EMAX = 2048;    // row positions whose tail cursors are held in LDS at a time
 static constexpr int MAX_PER_THREAD = 16;  // provisional entries per thread in the final compaction
+static constexpr int TAIL_ILP = 4;         // tail entries a wave keeps in flight
+static constexpr int TAIL_CH = 2;          // 64-rater pieces requested ahead per entry
+// the tail is accumulated in Q7.24 fixed point with integer LDS atomics (ds_add_u32; the float form
+// ds_add_f32 measured ~10x slower here): |sum| <= 1, each product is quantised with error <= 2^-25,
+// which the per-common-item term of row_eps covers
+static constexpr float TAIL_FIX = 16777216.0f;
+static constexpr float TAIL_UNFIX = 1.0f / 16777216.0f;
 
 __device__ __forceinline__ int sim_bin(float x) {
     int b = (int)floorf((x + 1.0f) * (NBINS / 2));
@@ -97,6 +105,7 @@ __global__ void __launch_bounds__(TPB) k_tail_select(float* __restrict__ S, int6
                                                      float* __restrict__ cand_approx, int32_t* __restrict__ cand_cnt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* tile = reinterpret_cast<float*>(smem);                // [TCOLS]
+    int32_t* itile = reinterpret_cast<int32_t*>(smem);            // the same tile while it accumulates the tail
     uint32_t* hist = reinterpret_cast<uint32_t*>(tile + TCOLS);   // [NBINS]
     int64_t* e_cur = reinterpret_cast<int64_t*>(hist + NBINS);    // [EMAX] cursor into it_user / it_pre
     int64_t* e_end = e_cur + EMAX;                                // [EMAX]
@@ -142,69 +151,137 @@ __global__ void __launch_bounds__(TPB) k_tail_select(float* __restrict__ S, int6
         const int32_t ne = s_ne;
         for (int32_t t0 = 0; t0 < U; t0 += TCOLS) {
             const int32_t t1 = min(U, t0 + TCOLS);
+            // this thread's 20 columns of the tile: float4 j covers columns t0 + 4 (tid + 1024 j) .. + 3.
+            // S rows are padded to ld (a multiple of 128) with zeros, so whole float4s can be read; the
+            // loads are issued first so that their HBM latency hides behind the tail accumulation
+            float4 sx[TCOLS / (4 * TPB)];
+            if (last_chunk) {
+#pragma unroll
+                for (int j = 0; j < TCOLS / (4 * TPB); ++j) {
+                    const int64_t v0 = (int64_t)t0 + 4 * (threadIdx.x + TPB * j);
+                    sx[j] = (v0 < ld) ? *reinterpret_cast<const float4*>(row + v0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
             if (ne > 0) {
-                for (int32_t c = threadIdx.x; c < t1 - t0; c += TPB) tile[c] = 0.0f;
+                for (int32_t c = threadIdx.x; c < t1 - t0; c += TPB) itile[c] = 0;
                 __syncthreads();
-                for (int32_t e = wave; e < ne; e += TPB / 64) {  // one wave per tail entry
-                    int64_t q = e_cur[e];
-                    const int64_t qe = e_end[e];
-                    const float x = e_x[e];
-                    while (q < qe) {
-                        const int64_t qq = q + lane;
-                        int32_t v = 0x7fffffff;
-                        float y = 0.f;
-                        if (qq < qe) {
-                            v = T.it_user[qq];
-                            y = T.it_pre[qq];
-                        }
-                        const bool in = v < t1;
-                        if (in) atomicAdd(&tile[v - t0], x * y);
-                        const int n_in = __popcll(__ballot(in));
-                        q += n_in;
-                        if (n_in < 64) break;  // reached the tile's end (raters ascend) or the list's end
+                // one wave per tail entry; TAIL_ILP entries x TAIL_CH 64-rater pieces are requested before any
+                // is consumed (the loop is latency-bound: rater lists are short and come from L2/HBM)
+                for (int32_t e0 = wave; e0 < ne; e0 += TAIL_ILP * (TPB / 64)) {
+                    int64_t q[TAIL_ILP], qe[TAIL_ILP];
+                    float x[TAIL_ILP];
+                    bool live[TAIL_ILP];
+#pragma unroll
+                    for (int j = 0; j < TAIL_ILP; ++j) {
+                        const int32_t e = e0 + j * (TPB / 64);
+                        live[j] = e < ne;
+                        q[j] = live[j] ? e_cur[e] : 0;
+                        qe[j] = live[j] ? e_end[e] : 0;
+                        x[j] = live[j] ? e_x[e] : 0.f;
+                        live[j] = live[j] && q[j] < qe[j];
                     }
-                    if (lane == 0) e_cur[e] = q;
+                    bool any_live = true;
+                    while (any_live) {
+                        int32_t v[TAIL_ILP][TAIL_CH];
+                        float y[TAIL_ILP][TAIL_CH];
+#pragma unroll
+                        for (int j = 0; j < TAIL_ILP; ++j)
+#pragma unroll
+                            for (int k = 0; k < TAIL_CH; ++k) {
+                                const int64_t qq = q[j] + 64 * k + lane;
+                                v[j][k] = 0x7fffffff;
+                                y[j][k] = 0.f;
+                                if (live[j] && qq < qe[j]) {
+                                    v[j][k] = T.it_user[qq];
+                                    y[j][k] = T.it_pre[qq];
+                                }
+                            }
+                        any_live = false;
+#pragma unroll
+                        for (int j = 0; j < TAIL_ILP; ++j) {
+                            if (!live[j]) continue;  // wave-uniform
+#pragma unroll
+                            for (int k = 0; k < TAIL_CH; ++k) {
+                                if (!live[j]) break;
+                                const bool in = v[j][k] < t1;
+                                if (in) atomicAdd(&itile[v[j][k] - t0], __float2int_rn(x[j] * y[j][k] * TAIL_FIX));
+                                const int n_in = __popcll(__ballot(in));
+                                q[j] += n_in;
+                                // fewer than 64 inside: reached the tile's end (raters ascend) or the list's end
+                                live[j] = (n_in == 64) && q[j] < qe[j];
+                            }
+                            any_live = any_live || live[j];
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < TAIL_ILP; ++j) {
+                        const int32_t e = e0 + j * (TPB / 64);
+                        if (e < ne && lane == 0) e_cur[e] = q[j];
+                    }
                 }
                 __syncthreads();
             }
             if (!last_chunk) {
                 if (ne > 0) {  // S += this chunk's tail part
-                    for (int32_t c = threadIdx.x; c < t1 - t0; c += TPB) row[t0 + c] += tile[c];
+                    for (int32_t c = threadIdx.x; c < t1 - t0; c += TPB) row[t0 + c] += (float)itile[c] * TAIL_UNFIX;
                     __syncthreads();
                 }
                 continue;
             }
-            // final values of the tile -> LDS, cumulative histogram
-            for (int32_t c = threadIdx.x * 4; c < t1 - t0; c += TPB * 4) {
-                const int32_t v0 = t0 + c;
-                if (v0 + 3 < t1) {
-                    float4 x = *reinterpret_cast<const float4*>(row + v0);
-                    if (ne > 0) { x.x += tile[c]; x.y += tile[c + 1]; x.z += tile[c + 2]; x.w += tile[c + 3]; }
-                    tile[c] = x.x; tile[c + 1] = x.y; tile[c + 2] = x.z; tile[c + 3] = x.w;
-                    if (v0 + 0 != u) atomicAdd(&hist[sim_bin(x.x)], 1u);
-                    if (v0 + 1 != u) atomicAdd(&hist[sim_bin(x.y)], 1u);
-                    if (v0 + 2 != u) atomicAdd(&hist[sim_bin(x.z)], 1u);
-                    if (v0 + 3 != u) atomicAdd(&hist[sim_bin(x.w)], 1u);
-                } else {
-                    for (int32_t v = v0; v < t1; ++v) {
-                        float x = row[v];
-                        if (ne > 0) x += tile[v - t0];
-                        tile[v - t0] = x;
-                        if (v != u) atomicAdd(&hist[sim_bin(x)], 1u);
+            // final values of this thread's columns (registers)
+            if (ne > 0) {
+#pragma unroll
+                for (int j = 0; j < TCOLS / (4 * TPB); ++j) {
+                    const int32_t c = 4 * (threadIdx.x + TPB * j);
+                    if (c < t1 - t0) {  // (t1 - t0 is a multiple of 4 except for the last tile: guard per element below)
+                        sx[j].x += (float)itile[c] * TAIL_UNFIX;
+                        if (c + 1 < t1 - t0) sx[j].y += (float)itile[c + 1] * TAIL_UNFIX;
+                        if (c + 2 < t1 - t0) sx[j].z += (float)itile[c + 2] * TAIL_UNFIX;
+                        if (c + 3 < t1 - t0) sx[j].w += (float)itile[c + 3] * TAIL_UNFIX;
                     }
+                }
+            }
+            // cumulative histogram.  Only values >= the current threshold can matter for the k-th largest
+            // (the threshold never exceeds it), which also keeps the LDS atomics off the crowded bins near 0.
+            // First tile: a 1/8 subsample bootstraps a valid threshold (the k-th largest of a subset is a
+            // lower bound of the k-th largest of the row).
+            float floor_thr = (t0 == 0) ? -INFINITY : s_thr;
+            for (int pass = (t0 == 0 ? 0 : 1); pass < 2; ++pass) {
+                const bool mine = (t0 != 0) || (((threadIdx.x & 7) == 0) == (pass == 0));
+                if (mine) {
+#pragma unroll
+                    for (int j = 0; j < TCOLS / (4 * TPB); ++j) {
+                        const int32_t v0 = t0 + 4 * (threadIdx.x + TPB * j);
+                        const float xs[4] = {sx[j].x, sx[j].y, sx[j].z, sx[j].w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int32_t v = v0 + i;
+                            if (v < t1 && v != u && xs[i] >= floor_thr) atomicAdd(&hist[sim_bin(xs[i])], 1u);
+                        }
+                    }
+                }
+                if (t0 == 0 && pass == 0) {
+                    __syncthreads();
+                    block_threshold(hist, wtot, &s_thr, kk, eps);
+                    floor_thr = s_thr;
                 }
             }
             __syncthreads();
             block_threshold(hist, wtot, &s_thr, kk, eps);
             const float thr = s_thr;  // valid for every column seen so far; it can only rise later
-            for (int32_t c = threadIdx.x; c < t1 - t0; c += TPB) {
-                const float x = tile[c];
-                const int32_t v = t0 + c;
-                if (v != u && x >= thr) {
-                    const uint32_t pos = atomicAdd(&s_count, 1u);
-                    if (pos < (uint32_t)cap) {
-                        out_idx[pos] = v;
-                        out_apx[pos] = x;
+#pragma unroll
+            for (int j = 0; j < TCOLS / (4 * TPB); ++j) {
+                const int32_t v0 = t0 + 4 * (threadIdx.x + TPB * j);
+                const float xs[4] = {sx[j].x, sx[j].y, sx[j].z, sx[j].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int32_t v = v0 + i;
+                    if (v < t1 && v != u && xs[i] >= thr) {
+                        const uint32_t pos = atomicAdd(&s_count, 1u);
+                        if (pos < (uint32_t)cap) {
+                            out_idx[pos] = v;
+                            out_apx[pos] = xs[i];
+                        }
                     }
                 }
             }
@@ -255,6 +332,7 @@ void launch_tail_select(const Train& tr, const int32_t* d_colmap, bool has_tail,
     const int32_t U = tr.U;
     int32_t kk = k < U - 1 ? k : U - 1;
     if (kk < 1) kk = 1;
+    if (getenv("KNNCF_DEBUG_NO_TAIL")) has_tail = false;  // TIMING EXPERIMENT ONLY (wrong results)
     TailArgs T{tr.u_ptr.p, tr.s_col.p, tr.s_pre.p, d_colmap, tr.i_ptr.p, tr.it_user.p, tr.it_pre.p, has_tail ? 1 : 0};
     const size_t smem = (size_t)TCOLS * 4 + (size_t)NBINS * 4 + (size_t)EMAX * (8 + 8 + 4);
     static bool attr_set = false;
