@@ -92,6 +92,8 @@ typedef struct knncf_timings {
     double max_bound_violation;    /* KNNCF_FLAG_VERIFY_BOUND: max(|approx-exact| - eps), <= 0 when the bound holds */
     int64_t head_items;            /* dense head width used by the last build */
     double tail_pair_updates;      /* sum over tail items of (raters in panel) x (raters) */
+    double rerank_row_bytes;       /* K6b algorithmic traffic: 12 B x ratings of every re-ranked candidate */
+    double select_row_bytes;       /* K6 algorithmic traffic: 4 B x (rows x users) similarity panel entries read */
 } knncf_timings;
 
 const char* knncf_version(void);
@@ -117,6 +119,7 @@ int knncf_global_avg(knncf_handle* h, double* out);                 /* average :
 int knncf_user_avg(knncf_handle* h, int32_t user, double* out);     /* computeUserAvg(train)(user, _) */
 int knncf_item_avg(knncf_handle* h, int32_t item, double* out);     /* computeItemAvg(train)(_, item) */
 int knncf_item_avg_dev(knncf_handle* h, int32_t item, double* out); /* computeItemAvgDev(train)(_, item) :193 */
+int knncf_item_avg_dev_rdd(knncf_handle* h, int32_t item, double* out); /* itemsAvgDevSpark(train)(_, item) :350 */
 /* the similarity function on a fresh closure: sim(train)(u, v) */
 int knncf_similarity(knncf_handle* h, int32_t u, int32_t v, double* out);
 /* getSimilarity(train, k, sim)(u, v): sim if v is one of u's k nearest, else 0 :634-648 */

@@ -8,6 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "obj")
 LIB = os.path.join(HERE, "libknncf.so")
+CLI = os.path.join(HERE, "knncf")
 SOURCES = ["api.cpp", "prep.hip", "sort_util.hip", "gemm.hip", "select.hip", "rerank.hip", "predict.hip", "neighbours.hip"]
 HEADERS = ["common.h", "engine.h", os.path.join("..", "..", "include", "knncf.h")]
 # -ffp-contract=off: the fp64 kernels must round exactly like the reference's JVM arithmetic (no FMA)
@@ -59,6 +60,14 @@ def build(force=False, verbose=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    # native entry points (predict.Baseline / Personalized / kNN, distributed.DistributedBaseline): plain C++
+    # over the C ABI only
+    cli_src = os.path.join(CSRC, "cli.cpp")
+    if force or _stale(CLI, [cli_src, LIB, os.path.join(HERE, "..", "include", "knncf.h")]):
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-o", CLI, cli_src, "-L" + HERE, "-lknncf", "-Wl,-rpath,$ORIGIN"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"cli build failed:\n{r.stdout}\n{r.stderr}")
     return LIB
 
 

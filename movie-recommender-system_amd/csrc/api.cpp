@@ -224,7 +224,7 @@ int32_t choose_head(knncf_handle* h, int32_t rows_total) {
         H = (int32_t)std::min<int64_t>(h->cfg.head_items, I);
     } else {
         const double RATE_DENSE = 1.1e15;   // marginal flop/s of k_gemm_nt_bf16 per extra dense column (measured)
-        const double RATE_SPARSE = 1.2e11;  // tail pair products per second through LDS atomics (k_tail_select, measured)
+        const double RATE_SPARSE = 3.0e11;  // marginal tail pair products per second through LDS atomics (k_tail_select, measured)
         const double frac = (double)rows_total / (double)tr.U;
         const double U_pad = (double)round_up(tr.U, 128);
         double best = 1e300;
@@ -275,7 +275,7 @@ void build_neighbors(knncf_handle* h, int32_t count) {
     size_t held = 0;
     for (int s = 0; s < 2; ++s) held += h->S[s].bytes() + h->Apanel[s].bytes();
     int64_t budget = h->cfg.workspace_bytes > 0 ? h->cfg.workspace_bytes / 2
-                                                : (int64_t)std::min<size_t>((size_t)12 << 30, (free_b + held) / 5);
+                                                : (int64_t)std::min<size_t>((size_t)20 << 30, (free_b + held) / 5);
     int64_t per_row = U_pad * 4 + K_pad * 2;
     int64_t R = std::max<int64_t>(128, (budget / per_row) / 128 * 128);
     R = std::min<int64_t>(R, round_up(count, 128));
@@ -296,6 +296,7 @@ void build_neighbors(knncf_handle* h, int32_t count) {
     h->sel.cand_approx.ensure((size_t)R * cap);
     h->sel.cand_cnt.ensure(R);
     h->sel.stats.ensure(4);
+    KN_HIP(hipMemsetAsync(h->sel.stats.p, 0, 4 * sizeof(double), st));  // [0] bound check, [1] candidate row entries
     if (h->pinned_cap < (size_t)count) {
         if (h->pinned_cnt) KN_HIP(hipHostFree(h->pinned_cnt));
         h->pinned_cnt = nullptr;
@@ -336,6 +337,7 @@ void build_neighbors(knncf_handle* h, int32_t count) {
             launch_tail_select(tr, h->colmap.p, head < tr.I, h->S[slot].p, U_pad, rows, d_rows, nt.k, eps, cap,
                                h->sel.cand_idx.p, h->sel.cand_approx.p, h->sel.cand_cnt.p, sc);
             h->tm.tail_pair_updates += h->tail_pairs_full * ((double)rows / (double)tr.U);
+            h->tm.select_row_bytes += 4.0 * (double)rows * (double)tr.U;
         }
         if (overlap) KN_HIP(hipEventRecord(h->ev_consumed[slot], sc));
         {
@@ -373,11 +375,13 @@ void build_neighbors(knncf_handle* h, int32_t count) {
             h->tm.fallback_rows += 1;
         }
     }
-    if (verify) {
-        unsigned long long bits = 0;
-        KN_HIP(hipMemcpyAsync(&bits, h->sel.stats.p, sizeof(bits), hipMemcpyDeviceToHost, st));
+    {
+        unsigned long long two[2] = {0, 0};
+        KN_HIP(hipMemcpyAsync(two, h->sel.stats.p, sizeof(two), hipMemcpyDeviceToHost, st));
         KN_HIP(hipStreamSynchronize(st));
-        if (bits != 0) {
+        h->tm.rerank_row_bytes += 12.0 * (double)two[1];
+        const unsigned long long bits = two[0];
+        if (verify && bits != 0) {
             double shifted;
             memcpy(&shifted, &bits, sizeof(double));
             h->tm.max_bound_violation = std::max(h->tm.max_bound_violation, shifted - 4.0);
@@ -615,6 +619,15 @@ int knncf_item_avg_dev(knncf_handle* h, int32_t item, double* out) {
         KN_REQUIRE(out, KNNCF_E_INVALID, "null out");
         int32_t d = dense_item(h, item);
         *out = d >= 0 ? fetch(h, h->tr.item_dev_hash.p, d) : 0.0;
+    });
+}
+
+int knncf_item_avg_dev_rdd(knncf_handle* h, int32_t item, double* out) {
+    return guarded(h, [&] {
+        require_fitted(h);
+        KN_REQUIRE(out, KNNCF_E_INVALID, "null out");
+        int32_t d = dense_item(h, item);
+        *out = d >= 0 ? fetch(h, h->tr.item_dev_file.p, d) : 0.0;
     });
 }
 

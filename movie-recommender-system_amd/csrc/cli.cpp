@@ -1,0 +1,430 @@
+// cli.cpp — native `knncf` entry points with the reference's CLI and JSON-answer surface.
+//
+//   knncf baseline              == predict.Baseline              (src/main/scala/predict/Baseline.scala)
+//   knncf personalized          == predict.Personalized          (predict/Personalized.scala)
+//   knncf knn                   == predict.kNN                   (predict/kNN.scala)
+//   knncf distributed-baseline  == distributed.DistributedBaseline (distributed/DistributedBaseline.scala)
+//   knncf load-check            parses a ratings file like shared.predictions.load and prints the row count
+//
+// Flags are Scallop's long options of the reference: --train --test --separator --num_measurements
+// --json [--master] (+ additive: --k, --device).  Output: the same JSON keys and nesting, 4-space indent,
+// printed and (with --json) saved.  Every number comes from libknncf.so through the C ABI
+// (include/knncf.h); this file contains no arithmetic of the path besides mean/std of the timings
+// (shared/predictions.scala:18-25).
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <chrono>
+#include <fstream>
+#include <functional>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/knncf.h"
+
+namespace {
+
+struct Ratings {
+    std::vector<int32_t> users, items;
+    std::vector<double> ratings;
+    int64_t size() const { return (int64_t)users.size(); }
+};
+
+std::string trim(const std::string& s) {
+    size_t b = 0, e = s.size();
+    while (b < e && (unsigned char)s[b] <= ' ') ++b;  // String.trim: code points <= U+0020
+    while (e > b && (unsigned char)s[e - 1] <= ' ') --e;
+    return s.substr(b, e - b);
+}
+
+// Scala's s.toInt: optional sign, decimal digits only, must fit an Int
+bool parse_int(const std::string& s, int32_t* out) {
+    if (s.empty()) return false;
+    size_t i = 0;
+    bool neg = false;
+    if (s[0] == '-' || s[0] == '+') { neg = s[0] == '-'; i = 1; }
+    if (i >= s.size()) return false;
+    int64_t v = 0;
+    for (; i < s.size(); ++i) {
+        if (s[i] < '0' || s[i] > '9') return false;
+        v = v * 10 + (s[i] - '0');
+        if (v > 2147483648ll) return false;
+    }
+    if (neg) v = -v;
+    if (v < -2147483648ll || v > 2147483647ll) return false;
+    *out = (int32_t)v;
+    return true;
+}
+
+// load shared/predictions.scala:35-49: split on the separator (used literally here; the reference passes
+// it to String.split as a regex, "\t" and "," mean the same either way), trim every column, keep the line
+// iff column 0 parses as an Int (header lines are dropped silently), columns 1 and 2 must then parse
+// (the reference throws NumberFormatException / ArrayIndexOutOfBounds: we fail loudly too)
+bool load_ratings(const std::string& path, const std::string& sep, Ratings* out, std::string* err) {
+    std::ifstream f(path);
+    if (!f) { *err = "cannot open " + path; return false; }
+    std::string line;
+    int64_t lineno = 0;
+    while (std::getline(f, line)) {
+        ++lineno;
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        std::vector<std::string> cols;
+        size_t pos = 0;
+        while (true) {
+            size_t q = sep.empty() ? std::string::npos : line.find(sep, pos);
+            if (q == std::string::npos) { cols.push_back(line.substr(pos)); break; }
+            cols.push_back(line.substr(pos, q - pos));
+            pos = q + sep.size();
+        }
+        while (cols.size() > 1 && cols.back().empty()) cols.pop_back();  // String.split drops trailing empties
+        int32_t u;
+        if (!parse_int(trim(cols[0]), &u)) continue;
+        int32_t i;
+        char* endp = nullptr;
+        if (cols.size() < 3 || !parse_int(trim(cols[1]), &i)) {
+            *err = path + ":" + std::to_string(lineno) + ": malformed rating row";
+            return false;
+        }
+        std::string rs = trim(cols[2]);
+        double r = strtod(rs.c_str(), &endp);
+        if (rs.empty() || *endp != '\0') {
+            *err = path + ":" + std::to_string(lineno) + ": malformed rating value";
+            return false;
+        }
+        out->users.push_back(u);
+        out->items.push_back(i);
+        out->ratings.push_back(r);
+    }
+    return true;
+}
+
+// ---- tiny ordered JSON writer (ujson.write(obj, 4) look) --------------------------------------------
+struct Json {
+    enum Kind { NUM, STR, OBJ, ARR, NUL } kind = NUL;
+    double num = 0;
+    std::string str;
+    std::vector<std::pair<std::string, Json>> obj;
+    std::vector<Json> arr;
+    static Json Num(double v) { Json j; j.kind = NUM; j.num = v; return j; }
+    static Json Str(const std::string& s) { Json j; j.kind = STR; j.str = s; return j; }
+    static Json Obj() { Json j; j.kind = OBJ; return j; }
+    static Json Arr() { Json j; j.kind = ARR; return j; }
+    Json& set(const std::string& k, const Json& v) { obj.push_back({k, v}); return *this; }
+    Json& push(const Json& v) { arr.push_back(v); return *this; }
+};
+
+std::string num_repr(double v) {
+    if (isnan(v) || isinf(v)) return "null";
+    if (v == floor(v) && fabs(v) < 1e15) {  // ujson prints integral doubles without a fraction
+        char b[64];
+        snprintf(b, sizeof b, "%.0f", v);
+        return b;
+    }
+    for (int p = 15; p <= 17; ++p) {  // shortest representation that round-trips
+        char b[64];
+        snprintf(b, sizeof b, "%.*g", p, v);
+        if (strtod(b, nullptr) == v) return b;
+    }
+    char b[64];
+    snprintf(b, sizeof b, "%.17g", v);
+    return b;
+}
+
+void write_json(const Json& j, int depth, std::ostringstream& o) {
+    std::string pad((size_t)depth * 4, ' '), pad1((size_t)(depth + 1) * 4, ' ');
+    switch (j.kind) {
+        case Json::NUM: o << num_repr(j.num); break;
+        case Json::NUL: o << "null"; break;
+        case Json::STR: {
+            o << '"';
+            for (char c : j.str) {
+                if (c == '"' || c == '\\') o << '\\' << c;
+                else if (c == '\n') o << "\\n";
+                else if (c == '\t') o << "\\t";
+                else o << c;
+            }
+            o << '"';
+            break;
+        }
+        case Json::OBJ:
+            o << "{\n";
+            for (size_t i = 0; i < j.obj.size(); ++i) {
+                o << pad1 << '"' << j.obj[i].first << "\": ";
+                write_json(j.obj[i].second, depth + 1, o);
+                o << (i + 1 < j.obj.size() ? ",\n" : "\n");
+            }
+            o << pad << "}";
+            break;
+        case Json::ARR:
+            o << "[\n";
+            for (size_t i = 0; i < j.arr.size(); ++i) {
+                o << pad1;
+                write_json(j.arr[i], depth + 1, o);
+                o << (i + 1 < j.arr.size() ? ",\n" : "\n");
+            }
+            o << pad << "]";
+            break;
+    }
+}
+
+// mean / std shared/predictions.scala:18-25 (population standard deviation)
+double mean(const std::vector<double>& s) {
+    if (s.empty()) return 0.0;
+    double a = s[0];
+    for (size_t i = 1; i < s.size(); ++i) a = a + s[i];
+    return a / (double)s.size();
+}
+double stddev(const std::vector<double>& s) {
+    if (s.empty()) return 0.0;
+    double m = mean(s), a = 0.0;
+    for (double x : s) a = a + (m - x) * (m - x);
+    return sqrt(a / (double)s.size());
+}
+Json timing_obj(const std::vector<double>& t) {
+    return Json::Obj().set("average (ms)", Json::Num(mean(t))).set("stddev (ms)", Json::Num(stddev(t)));
+}
+
+struct Fail {
+    std::string msg;
+};
+
+void check(knncf_handle* h, int st, const char* what) {
+    if (st != KNNCF_OK) throw Fail{std::string(what) + ": " + (h ? knncf_last_error(h) : knncf_status_string(st))};
+}
+
+struct Engine {
+    knncf_handle* h = nullptr;
+    Engine(int device, int k, int sim) {
+        knncf_config cfg;
+        memset(&cfg, 0, sizeof cfg);
+        cfg.struct_size = sizeof cfg;
+        cfg.device = device;
+        cfg.k = k;
+        cfg.similarity = sim;
+        cfg.shard_count = 1;
+        int st = knncf_create(&cfg, &h);
+        if (st != KNNCF_OK) throw Fail{std::string("knncf_create: ") + knncf_status_string(st)};
+    }
+    ~Engine() { knncf_destroy(h); }
+    Engine(const Engine&) = delete;
+    void fit(const Ratings& r) { check(h, knncf_fit(h, r.users.data(), r.items.data(), r.ratings.data(), r.size()), "fit"); }
+    double mae(int pred, const Ratings& t) {
+        double m = 0;
+        check(h, knncf_mae(h, pred, t.users.data(), t.items.data(), t.ratings.data(), t.size(), &m), "mae");
+        return m;
+    }
+    double predict(int pred, int32_t u, int32_t i) {
+        double p = 0;
+        check(h, knncf_predict(h, pred, u, i, &p), "predict");
+        return p;
+    }
+};
+
+// timingInMs shared/predictions.scala:11-16 around `f` (closure construction = fit included)
+double timed_ms(const std::function<void()>& f) {
+    auto a = std::chrono::steady_clock::now();
+    f();
+    auto b = std::chrono::steady_clock::now();
+    return std::chrono::duration<double, std::milli>(b - a).count();
+}
+
+struct Args {
+    std::string cmd, train, test, separator = "\t", json, master;
+    int num_measurements = 0, k = 300, device = 0;
+};
+
+Json meta(const Args& a, bool with_master) {
+    Json m = Json::Obj();
+    m.set("1.Train", Json::Str(a.train)).set("2.Test", Json::Str(a.test));
+    if (with_master) m.set("3.Master", Json::Str(a.master)).set("4.Measurements", Json::Num(a.num_measurements));
+    else m.set("3.Measurements", Json::Num(a.num_measurements));
+    return m;
+}
+
+Json run_baseline(const Args& a, const Ratings& train, const Ratings& test) {  // predict/Baseline.scala:45-124
+    const int kinds[4] = {KNNCF_PRED_GLOBAL_AVG, KNNCF_PRED_USER_AVG, KNNCF_PRED_ITEM_AVG, KNNCF_PRED_BASELINE};
+    std::vector<double> times[4];
+    for (int p = 0; p < 4; ++p)
+        for (int m = 0; m < a.num_measurements; ++m)
+            times[p].push_back(timed_ms([&] { Engine e(a.device, a.k, KNNCF_SIM_COSINE); e.fit(train); e.mae(kinds[p], test); }));
+    Engine e(a.device, a.k, KNNCF_SIM_COSINE);
+    e.fit(train);
+    double dev = 0;
+    check(e.h, knncf_item_avg_dev(e.h, 1, &dev), "item_avg_dev");
+    Json out = Json::Obj();
+    out.set("Meta", meta(a, false));
+    out.set("B.1", Json::Obj()
+                       .set("1.GlobalAvg", Json::Num(e.predict(KNNCF_PRED_GLOBAL_AVG, 1, 1)))
+                       .set("2.User1Avg", Json::Num(e.predict(KNNCF_PRED_USER_AVG, 1, 1)))
+                       .set("3.Item1Avg", Json::Num(e.predict(KNNCF_PRED_ITEM_AVG, 1, 1)))
+                       .set("4.Item1AvgDev", Json::Num(dev))
+                       .set("5.PredUser1Item1", Json::Num(e.predict(KNNCF_PRED_BASELINE, 1, 1))));
+    out.set("B.2", Json::Obj()
+                       .set("1.GlobalAvgMAE", Json::Num(e.mae(KNNCF_PRED_GLOBAL_AVG, test)))
+                       .set("2.UserAvgMAE", Json::Num(e.mae(KNNCF_PRED_USER_AVG, test)))
+                       .set("3.ItemAvgMAE", Json::Num(e.mae(KNNCF_PRED_ITEM_AVG, test)))
+                       .set("4.BaselineMAE", Json::Num(e.mae(KNNCF_PRED_BASELINE, test))));
+    out.set("B.3", Json::Obj()
+                       .set("1.GlobalAvg", timing_obj(times[0]))
+                       .set("2.UserAvg", timing_obj(times[1]))
+                       .set("3.ItemAvg", timing_obj(times[2]))
+                       .set("4.Baseline", timing_obj(times[3])));
+    return out;
+}
+
+Json run_knn(const Args& a, const Ratings& train, const Ratings& test) {  // predict/kNN.scala:42-87
+    std::vector<double> times;
+    for (int m = 0; m < a.num_measurements; ++m)
+        times.push_back(timed_ms([&] { Engine e(a.device, a.k, KNNCF_SIM_COSINE); e.fit(train); e.mae(KNNCF_PRED_KNN, test); }));
+    Engine e(a.device, 10, KNNCF_SIM_COSINE);
+    e.fit(train);
+    auto ksim = [&](int32_t u, int32_t v) {  // every answer builds fresh closures in the reference (:66-70)
+        check(e.h, knncf_reset_neighbors(e.h), "reset");
+        double s = 0;
+        check(e.h, knncf_knn_similarity(e.h, u, v, &s), "knn_similarity");
+        return s;
+    };
+    Json out = Json::Obj();
+    out.set("Meta", meta(a, false));
+    Json n1 = Json::Obj();
+    n1.set("1.k10u1v1", Json::Num(ksim(1, 1))).set("2.k10u1v864", Json::Num(ksim(1, 864))).set("3.k10u1v886", Json::Num(ksim(1, 886)));
+    check(e.h, knncf_reset_neighbors(e.h), "reset");
+    n1.set("4.PredUser1Item1", Json::Num(e.predict(KNNCF_PRED_KNN, 1, 1)));
+    out.set("N.1", n1);
+    Json maes = Json::Arr();
+    for (int k : {10, 30, 50, 100, 200, 300, 400, 800, 943}) {
+        check(e.h, knncf_set_k(e.h, k), "set_k");
+        maes.push(Json::Arr().push(Json::Num(k)).push(Json::Num(e.mae(KNNCF_PRED_KNN, test))));
+    }
+    out.set("N.2", Json::Obj().set("1.kNN-Mae", maes));
+    out.set("N.3", Json::Obj().set("1.kNN", timing_obj(times)));
+    return out;
+}
+
+Json run_personalized(const Args& a, const Ratings& train, const Ratings& test) {  // predict/Personalized.scala:54-74
+    Json out = Json::Obj();
+    out.set("Meta", meta(a, false));
+    {
+        Engine one(a.device, a.k, KNNCF_SIM_ONE);
+        one.fit(train);
+        out.set("P.1", Json::Obj()
+                           .set("1.PredUser1Item1", Json::Num(one.predict(KNNCF_PRED_PERSONALIZED, 1, 1)))
+                           .set("2.OnesMAE", Json::Num(one.mae(KNNCF_PRED_PERSONALIZED, test))));
+    }
+    {
+        int32_t U = 0;
+        Engine cosv(a.device, 1, KNNCF_SIM_COSINE);
+        cosv.fit(train);
+        check(cosv.h, knncf_num_users(cosv.h, &U), "num_users");
+        check(cosv.h, knncf_set_k(cosv.h, U), "set_k");  // no neighbourhood cut == every other user is a neighbour
+        double s21 = 0;
+        check(cosv.h, knncf_similarity(cosv.h, 2, 1, &s21), "similarity");
+        out.set("P.2", Json::Obj()
+                           .set("1.AdjustedCosineUser1User2", Json::Num(s21))
+                           .set("2.PredUser1Item1", Json::Num(cosv.predict(KNNCF_PRED_KNN, 1, 1)))
+                           .set("3.AdjustedCosineMAE", Json::Num(cosv.mae(KNNCF_PRED_KNN, test))));
+    }
+    {
+        Engine jac(a.device, a.k, KNNCF_SIM_JACCARD);
+        jac.fit(train);
+        double s12 = 0;
+        check(jac.h, knncf_similarity(jac.h, 1, 2, &s12), "similarity");
+        Json nul;  // Jaccard-weighted prediction is not built (the reference's committed P.3 answers are stale)
+        out.set("P.3", Json::Obj().set("1.JaccardUser1User2", Json::Num(s12)).set("2.PredUser1Item1", nul).set("3.JaccardPersonalizedMAE", nul));
+    }
+    return out;
+}
+
+Json run_distributed(const Args& a, const Ratings& train, const Ratings& test) {  // distributed/DistributedBaseline.scala:45-83
+    std::vector<double> times;
+    for (int m = 0; m < a.num_measurements; ++m)
+        times.push_back(timed_ms([&] { Engine e(a.device, a.k, KNNCF_SIM_COSINE); e.fit(train); e.mae(KNNCF_PRED_BASELINE_RDD, test); }));
+    Engine e(a.device, a.k, KNNCF_SIM_COSINE);
+    e.fit(train);
+    double dev = 0;
+    check(e.h, knncf_item_avg_dev_rdd(e.h, 1, &dev), "item_avg_dev_rdd");
+    Json out = Json::Obj();
+    out.set("Meta", meta(a, true));
+    out.set("D.1", Json::Obj()
+                       .set("1.GlobalAvg", Json::Num(e.predict(KNNCF_PRED_GLOBAL_AVG, 1, 1)))
+                       .set("2.User1Avg", Json::Num(e.predict(KNNCF_PRED_USER_AVG, 1, 0)))
+                       .set("3.Item1Avg", Json::Num(e.predict(KNNCF_PRED_ITEM_AVG, 0, 1)))
+                       .set("4.Item1AvgDev", Json::Num(dev))
+                       .set("5.PredUser1Item1", Json::Num(e.predict(KNNCF_PRED_BASELINE_RDD, 1, 1)))
+                       .set("6.Mae", Json::Num(e.mae(KNNCF_PRED_BASELINE_RDD, test))));
+    out.set("D.2", Json::Obj().set("1.DistributedBaseline", timing_obj(times)));
+    return out;
+}
+
+int usage() {
+    fprintf(stderr,
+            "usage: knncf {baseline|personalized|knn|distributed-baseline|load-check} --train FILE --test FILE\n"
+            "             [--separator SEP] [--num_measurements N] [--json FILE] [--master M] [--k K] [--device D]\n");
+    return 2;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    if (argc < 2) return usage();
+    Args a;
+    a.cmd = argv[1];
+    for (int i = 2; i < argc; ++i) {
+        std::string k = argv[i];
+        auto need = [&](const char* name) -> std::string {
+            if (i + 1 >= argc) { fprintf(stderr, "[knncf] missing value for %s\n", name); exit(2); }
+            return argv[++i];
+        };
+        if (k == "--train") a.train = need("--train");
+        else if (k == "--test") a.test = need("--test");
+        else if (k == "--separator") a.separator = need("--separator");
+        else if (k == "--num_measurements") a.num_measurements = atoi(need("--num_measurements").c_str());
+        else if (k == "--json") a.json = need("--json");
+        else if (k == "--master") a.master = need("--master");
+        else if (k == "--k") a.k = atoi(need("--k").c_str());
+        else if (k == "--device") a.device = atoi(need("--device").c_str());
+        else { fprintf(stderr, "[knncf] unknown option %s\n", k.c_str()); return usage(); }
+    }
+    if (a.separator == "\\t") a.separator = "\t";
+    if (a.train.empty() || (a.test.empty() && a.cmd != "load-check")) { fprintf(stderr, "[knncf] --train and --test are required\n"); return usage(); }
+    Ratings train, test;
+    std::string err;
+    printf("\n******************************************************\n");
+    printf("Loading training data from: %s\n", a.train.c_str());
+    if (!load_ratings(a.train, a.separator, &train, &err)) { fprintf(stderr, "[knncf] %s\n", err.c_str()); return 1; }
+    if (a.cmd == "load-check") {
+        printf("rows: %lld\n", (long long)train.size());
+        if (train.size() > 0)
+            printf("first: %d %d %s\nlast: %d %d %s\n", train.users.front(), train.items.front(), num_repr(train.ratings.front()).c_str(),
+                   train.users.back(), train.items.back(), num_repr(train.ratings.back()).c_str());
+        return 0;
+    }
+    printf("Loading test data from: %s\n", a.test.c_str());
+    if (!load_ratings(a.test, a.separator, &test, &err)) { fprintf(stderr, "[knncf] %s\n", err.c_str()); return 1; }
+    try {
+        Json out;
+        if (a.cmd == "baseline") out = run_baseline(a, train, test);
+        else if (a.cmd == "knn") out = run_knn(a, train, test);
+        else if (a.cmd == "personalized") out = run_personalized(a, train, test);
+        else if (a.cmd == "distributed-baseline") out = run_distributed(a, train, test);
+        else return usage();
+        std::ostringstream o;
+        write_json(out, 0, o);
+        printf("%s\n", o.str().c_str());
+        if (!a.json.empty()) {
+            printf("Saving answers in: %s\n", a.json.c_str());
+            std::ofstream f(a.json);
+            f << o.str();
+        }
+    } catch (const Fail& f) {
+        fprintf(stderr, "[knncf] %s\n", f.msg.c_str());
+        return 1;
+    }
+    printf("\n");
+    return 0;
+}

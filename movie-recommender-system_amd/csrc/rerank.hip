@@ -148,7 +148,11 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// exact similarities of this wave's candidates (n_c <= 64); lane j returns candidate j's
+// exact similarities of this wave's candidates (n_c <= 64); lane j returns candidate j's.
+// The candidates' rows form one stream of 64-entry pieces; PIPE pieces are always in flight (the loop
+// is bound by the latency of these L2/HBM reads, not by their volume).
+static constexpr int PIPE = 4;
+
 template <class PreP>
 __device__ __forceinline__ double wave_sims(const Rows& R, lds_cu32 bits, lds_cu32 pref, PreP upre, int32_t ufirst,
                                             int32_t ulast, lds_f64 wb, int32_t my_v, int n_c, int lane) {
@@ -158,69 +162,70 @@ __device__ __forceinline__ double wave_sims(const Rows& R, lds_cu32 bits, lds_cu
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     double acc = 0.0;
     int32_t my_off = 0, my_cnt = 0, off = 0;
-    int j = 0;
-    int64_t base = __shfl(my_b, 0), eb = __shfl(my_e, 0);
-    int64_t p = base + lane;
-    int32_t c_cur = (p < eb) ? R.s_col[p] : 0x7fffffff;
-    double y_cur = (p < eb) ? R.s_pre[p] : 0.0;
-    while (j < n_c) {
-        // next piece of the stream: the same candidate's next 64 entries, or the next candidate's first
-        int nj = j;
-        int64_t nbase = base + 64, neb = eb;
-        if (nbase >= eb) {
-            nj = j + 1;
-            if (nj < n_c) {
-                nbase = __shfl(my_b, nj);
-                neb = __shfl(my_e, nj);
+    // fetch cursor (wave-uniform): candidate, piece start, row end
+    int fj = 0;
+    int64_t fbase = __shfl(my_b, 0), feb = __shfl(my_e, 0);
+    int pj[PIPE];        // candidate of the piece in slot d (n_c = empty slot)
+    int64_t pbase[PIPE], peb[PIPE];
+    int32_t pc[PIPE];
+    double py[PIPE];
+#pragma unroll
+    for (int d = 0; d < PIPE; ++d) {
+        pj[d] = fj; pbase[d] = fbase; peb[d] = feb;
+        pc[d] = 0x7fffffff; py[d] = 0.0;
+        if (fj < n_c) {
+            const int64_t q = fbase + lane;
+            if (q < feb) { pc[d] = R.s_col[q]; py[d] = R.s_pre[q]; }
+            fbase += 64;
+            if (fbase >= feb) {
+                ++fj;
+                if (fj < n_c) { fbase = __shfl(my_b, fj); feb = __shfl(my_e, fj); }
             }
         }
-        int32_t c_nxt = 0x7fffffff;
-        double y_nxt = 0.0;
-        if (nj < n_c) {
-            int64_t q = nbase + lane;
-            if (q < neb) {
-                c_nxt = R.s_col[q];
-                y_nxt = R.s_pre[q];
+    }
+    while (pj[0] < n_c) {
+#pragma unroll
+        for (int d = 0; d < PIPE; ++d) {
+            const int j = pj[d];
+            if (j < n_c) {  // wave-uniform
+                if (off + 64 > WBUF) {  // fold what has been collected; partial candidates continue in `acc`
+                    wave_sync();
+                    for (int32_t t = 0; t < my_cnt; ++t) acc = acc + wb[my_off + t];
+                    wave_sync();
+                    off = 0; my_off = 0; my_cnt = 0;
+                }
+                const int32_t c_cur = pc[d];
+                const double y_cur = py[d];
+                if (pbase[d] == __shfl(my_b, j) && lane == j) my_off = off;  // candidate j's products start here
+                const int32_t cmin = __shfl(c_cur, 0);
+                const int32_t cmax = __shfl(c_cur, (int)(min(peb[d] - 1, pbase[d] + 63) - pbase[d]));
+                if (cmin <= ulast && cmax >= ufirst) {  // otherwise the piece lies outside u's item range
+                    const bool valid = c_cur != 0x7fffffff;
+                    const uint32_t word = valid ? bits[c_cur >> 5] : 0u;
+                    const bool hit = (word >> (c_cur & 31)) & 1u;
+                    const unsigned long long mask = __ballot(hit);
+                    if (hit) {
+                        const int32_t idx = (int32_t)pref[c_cur >> 5] + __popc(word & ((1u << (c_cur & 31)) - 1u));
+                        wb[off + __popcll(mask & lt_mask)] = upre[idx] * y_cur;
+                    }
+                    const int32_t n = __popcll(mask);
+                    if (lane == j) my_cnt += n;
+                    off += n;
+                }
             }
-        }
-        if (off + 64 > WBUF) {  // fold what has been collected; partial candidates continue in `acc`
-            wave_sync();
-            for (int32_t t = 0; t < my_cnt; ++t) acc = acc + wb[my_off + t];
-            wave_sync();
-            off = 0; my_off = 0; my_cnt = 0;
-        }
-        const int32_t cmin = __shfl(c_cur, 0);
-        const int32_t cmax = __shfl(c_cur, (int)(min(eb - 1, base + 63) - base));
-        const bool rest_empty = cmin > ulast;  // everything from here on lies beyond u's last item
-        if (!rest_empty && cmax >= ufirst) {
-            const bool valid = c_cur != 0x7fffffff;
-            const uint32_t word = valid ? bits[c_cur >> 5] : 0u;
-            const bool hit = (word >> (c_cur & 31)) & 1u;
-            const unsigned long long mask = __ballot(hit);
-            if (hit) {
-                const int32_t idx = (int32_t)pref[c_cur >> 5] + __popc(word & ((1u << (c_cur & 31)) - 1u));
-                wb[off + __popcll(mask & lt_mask)] = upre[idx] * y_cur;
-            }
-            const int32_t n = __popcll(mask);
-            if (lane == j) my_cnt += n;
-            off += n;
-        }
-        if (rest_empty && nj == j) {  // skip the candidate's remaining pieces: restart the stream at j + 1
-            nj = j + 1;
-            c_nxt = 0x7fffffff;
-            y_nxt = 0.0;
-            if (nj < n_c) {
-                nbase = __shfl(my_b, nj);
-                neb = __shfl(my_e, nj);
-                int64_t q = nbase + lane;
-                if (q < neb) {
-                    c_nxt = R.s_col[q];
-                    y_nxt = R.s_pre[q];
+            // refill the slot with the next piece of the stream
+            pj[d] = fj; pbase[d] = fbase; peb[d] = feb;
+            pc[d] = 0x7fffffff; py[d] = 0.0;
+            if (fj < n_c) {
+                const int64_t q = fbase + lane;
+                if (q < feb) { pc[d] = R.s_col[q]; py[d] = R.s_pre[q]; }
+                fbase += 64;
+                if (fbase >= feb) {
+                    ++fj;
+                    if (fj < n_c) { fbase = __shfl(my_b, fj); feb = __shfl(my_e, fj); }
                 }
             }
         }
-        if (nj != j && lane == nj) my_off = off;  // candidate nj's products start here
-        j = nj; base = nbase; eb = neb; c_cur = c_nxt; y_cur = y_nxt;
     }
     wave_sync();
     for (int32_t t = 0; t < my_cnt; ++t) acc = acc + wb[my_off + t];
@@ -285,6 +290,7 @@ __global__ void __launch_bounds__(TPB) k_rerank(Rows R, const int64_t* __restric
     const int32_t* my_cand = cand_idx + (int64_t)r * cap;
     lds_f64 wb = (lds_f64)(wbuf + wave * WBUF);
     double worst = -1.0;
+    int64_t row_entries = 0;
     int32_t best = 0, pos = 0;
     __syncthreads();
     do {
@@ -296,7 +302,9 @@ __global__ void __launch_bounds__(TPB) k_rerank(Rows R, const int64_t* __restric
             const int32_t v = (lane < n_c) ? my_cand[pos + c0 + lane] : 0;
             double s;
             // Set1..Set4 iterate in file order and the memo history matters (N2, N6): scalar path
-            const bool small_v = (lane < n_c) && (R.u_ptr[v + 1] - R.u_ptr[v] <= 4);
+            const int64_t len_v = (lane < n_c) ? (R.u_ptr[v + 1] - R.u_ptr[v]) : 0;
+            row_entries += len_v;  // algorithmic traffic of this kernel: the candidates' rows (12 B per entry)
+            const bool small_v = (lane < n_c) && (len_v <= 4);
             if (nu > 4 && !__any(small_v)) {
                 s = pre_lds ? wave_sims(R, (lds_cu32)bits, (lds_cu32)pref, (lds_cf64)upre, ufirst, ulast, wb, v, n_c, lane)
                             : wave_sims(R, (lds_cu32)bits, (lds_cu32)pref, R.s_pre + ub, ufirst, ulast, wb, v, n_c, lane);
@@ -334,6 +342,8 @@ __global__ void __launch_bounds__(TPB) k_rerank(Rows R, const int64_t* __restric
         best = min(kk, best + take);
         pos += take;
     } while (pos < cnt);
+    for (int o = 32; o > 0; o >>= 1) row_entries += __shfl_xor(row_entries, o);
+    if (lane == 0 && row_entries > 0) atomicAdd(reinterpret_cast<unsigned long long*>(stats) + 1, (unsigned long long)row_entries);
     if (cand_approx) {
         // max over the grid of (|approx - exact| - eps); must stay <= 0
         for (int o = 32; o > 0; o >>= 1) worst = fmax(worst, __shfl_xor(worst, o));

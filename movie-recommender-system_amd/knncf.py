@@ -37,7 +37,8 @@ class Timings(C.Structure):
                 ("gemm_launches", C.c_int64), ("gemm_flops_executed", C.c_double),
                 ("gemm_flops_algorithmic", C.c_double), ("shortlist_total", C.c_int64),
                 ("fallback_rows", C.c_int64), ("max_bound_violation", C.c_double),
-                ("head_items", C.c_int64), ("tail_pair_updates", C.c_double)]
+                ("head_items", C.c_int64), ("tail_pair_updates", C.c_double),
+                ("rerank_row_bytes", C.c_double), ("select_row_bytes", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -53,7 +54,7 @@ class ShardView(C.Structure):
 EXPORTS = [
     "knncf_version", "knncf_status_string", "knncf_create", "knncf_destroy", "knncf_last_error",
     "knncf_fit", "knncf_fit_device", "knncf_num_users", "knncf_num_items", "knncf_global_avg",
-    "knncf_user_avg", "knncf_item_avg", "knncf_item_avg_dev", "knncf_similarity",
+    "knncf_user_avg", "knncf_item_avg", "knncf_item_avg_dev", "knncf_item_avg_dev_rdd", "knncf_similarity",
     "knncf_knn_similarity", "knncf_neighbors", "knncf_predict", "knncf_predict_batch",
     "knncf_predict_batch_device", "knncf_mae", "knncf_mae_device", "knncf_shard_view_get",
     "knncf_shard_commit", "knncf_get_timings", "knncf_reset_timings", "knncf_reset_neighbors",
@@ -113,7 +114,7 @@ def load_library():
     L.knncf_num_users.argtypes = [C.c_void_p, _i32p]
     L.knncf_num_items.argtypes = [C.c_void_p, _i32p]
     L.knncf_global_avg.argtypes = [C.c_void_p, _f64p]
-    for n in ("knncf_user_avg", "knncf_item_avg", "knncf_item_avg_dev"):
+    for n in ("knncf_user_avg", "knncf_item_avg", "knncf_item_avg_dev", "knncf_item_avg_dev_rdd"):
         getattr(L, n).argtypes = [C.c_void_p, C.c_int32, _f64p]
     for n in ("knncf_similarity", "knncf_knn_similarity"):
         getattr(L, n).argtypes = [C.c_void_p, C.c_int32, C.c_int32, _f64p]
@@ -228,6 +229,9 @@ class Engine:
 
     def item_avg_dev(self, i):
         return self._scalar(self._lib.knncf_item_avg_dev, i)
+
+    def item_avg_dev_rdd(self, i):
+        return self._scalar(self._lib.knncf_item_avg_dev_rdd, i)
 
     def similarity(self, u, v):
         return self._scalar(self._lib.knncf_similarity, u, v)

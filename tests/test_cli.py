@@ -1,0 +1,95 @@
+"""The native entry points (movie-recommender-system_amd/knncf, csrc/cli.cpp): the reference's CLI flags and
+JSON-answer surface (predict/Baseline.scala:86-124, predict/kNN.scala:59-87, predict/Personalized.scala:54-74,
+distributed/DistributedBaseline.scala:62-83).  Values are compared PARSED, against the CPU oracle."""
+import importlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "movie-recommender-system_amd", "knncf")
+
+
+@pytest.fixture(scope="module")
+def cli(pkg):
+    importlib.import_module(pkg.__name__ + ".build").build()
+    assert os.path.exists(CLI)
+    return CLI
+
+
+def test_loader_quirks(cli, tmp_path):
+    """load shared/predictions.scala:35-49: header and non-numeric-first-column lines are dropped silently,
+    columns are trimmed, a 4th column (timestamp) is ignored."""
+    p = tmp_path / "r.csv"
+    p.write_text("userId,movieId,rating,timestamp\n1,10,4.5,111\n 2 , 11 ,3.0,112\nfoo,1,1\n\n3,12,5\n")
+    out = subprocess.run([cli, "load-check", "--train", str(p), "--separator", ","], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "rows: 3" in out.stdout and "first: 1 10 4.5" in out.stdout and "last: 3 12 5" in out.stdout
+    bad = tmp_path / "bad.tsv"
+    bad.write_text("1\t2\n")  # cols(2) out of bounds in the reference -> exception; here: loud failure
+    out = subprocess.run([cli, "load-check", "--train", str(bad)], capture_output=True, text=True)
+    assert out.returncode != 0 and "malformed" in out.stderr
+    out = subprocess.run([cli, "knn", "--test", "x"], capture_output=True, text=True)
+    assert out.returncode == 2  # --train is required (Scallop exits on a missing required option)
+
+
+def _write(path, rs, sep="\t"):
+    with open(path, "w") as f:
+        for u, i, r in zip(rs.users, rs.items, rs.ratings):
+            f.write(f"{u}{sep}{i}{sep}{r:g}{sep}881250949\n")
+
+
+@pytest.mark.gpu
+def test_entry_points_against_oracle(cli, tmp_path, oracle, syn100k):
+    d = syn100k
+    tr, te = str(tmp_path / "u2.base"), str(tmp_path / "u2.test")
+    _write(tr, d.train)
+    _write(te, d.test)
+    m = oracle.Model(d.train.users, d.train.items, d.train.ratings)
+    T = (d.test.users, d.test.items, d.test.ratings)
+
+    def run(cmd, *extra):
+        js = str(tmp_path / f"{cmd}.json")
+        out = subprocess.run([cli, cmd, "--train", tr, "--test", te, "--json", js, "--num_measurements", "2", *extra],
+                             capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        return json.load(open(js))
+
+    b = run("baseline")
+    assert list(b) == ["Meta", "B.1", "B.2", "B.3"] and b["Meta"]["3.Measurements"] == 2
+    assert b["B.1"]["1.GlobalAvg"] == m.average()
+    assert b["B.1"]["2.User1Avg"] == m.users_avg(1)
+    assert b["B.1"]["3.Item1Avg"] == m.items_avg(1)
+    assert b["B.1"]["4.Item1AvgDev"] == m.items_avg_dev(1)
+    assert b["B.1"]["5.PredUser1Item1"] == m.predict(oracle.KIND_BASELINE, 1, 1)
+    for key, kind in (("1.GlobalAvgMAE", 0), ("2.UserAvgMAE", 1), ("3.ItemAvgMAE", 2), ("4.BaselineMAE", 3)):
+        assert b["B.2"][key] == pytest.approx(m.mae(kind, *T), abs=1e-12)
+    assert b["B.3"]["4.Baseline"]["average (ms)"] > 0
+
+    k = run("knn")
+    p10 = m.pipeline(oracle.SIM_COSINE, 10)
+    assert k["N.1"]["1.k10u1v1"] == 0
+    assert k["N.1"]["2.k10u1v864"] == p10.knn_similarity(1, 864)
+    assert k["N.1"]["3.k10u1v886"] == p10.knn_similarity(1, 886)
+    assert k["N.1"]["4.PredUser1Item1"] == m.pipeline(oracle.SIM_COSINE, 10).predict(1, 1)
+    assert [row[0] for row in k["N.2"]["1.kNN-Mae"]] == [10, 30, 50, 100, 200, 300, 400, 800, 943]
+    for kk, got in k["N.2"]["1.kNN-Mae"]:
+        if kk in (10, 300, 943):
+            assert got == pytest.approx(m.pipeline(oracle.SIM_COSINE, kk).mae(*T), abs=1e-9)
+    assert k["N.3"]["1.kNN"]["stddev (ms)"] >= 0
+
+    pz = run("personalized")
+    assert pz["P.1"]["2.OnesMAE"] == pytest.approx(m.pipeline(oracle.SIM_ONE, -1).mae(*T), abs=1e-12)
+    assert pz["P.2"]["1.AdjustedCosineUser1User2"] == m.fresh_similarity(oracle.SIM_COSINE, 2, 1)
+    assert pz["P.2"]["3.AdjustedCosineMAE"] == pytest.approx(m.pipeline(oracle.SIM_COSINE, -1).mae(*T), abs=1e-9)
+    assert pz["P.3"]["1.JaccardUser1User2"] == m.fresh_similarity(oracle.SIM_JACCARD, 1, 2)
+
+    dz = run("distributed-baseline", "--master", "local[4]")
+    assert dz["Meta"]["3.Master"] == "local[4]" and dz["Meta"]["4.Measurements"] == 2
+    assert dz["D.1"]["1.GlobalAvg"] == m.average()
+    assert dz["D.1"]["4.Item1AvgDev"] == m.items_avg_dev_spark(1)
+    assert dz["D.1"]["5.PredUser1Item1"] == m.predict(oracle.KIND_BASELINE_SPARK, 1, 1)
+    assert dz["D.1"]["6.Mae"] == pytest.approx(m.mae(oracle.KIND_BASELINE_SPARK, *T), abs=1e-12)
