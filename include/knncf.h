@@ -56,6 +56,7 @@ extern "C" {
  * are ~k instead of ~3k and the re-rank is 3.6x cheaper (measured).  |pre| <= 1, so fp16's range is ample.
  * This flag selects bf16 operands (the north_star's literal wording); results are identical either way. */
 #define KNNCF_FLAG_BF16_FILTER 4u
+#define KNNCF_FLAG_F32_PANEL 8u /* keep the similarity panel in fp32 (default fp16: half the HBM traffic, band + 2^-11) */
 #define KNNCF_FLAG_OVERLAP 2u      /* double-buffer the row blocks: GEMM/tail of block b+1 overlap select/re-rank of block b */
 
 typedef struct knncf_handle knncf_handle;

@@ -22,6 +22,7 @@ void launch_fallback_write(int32_t user, int32_t take, int32_t kcap, const uint3
                            const double* d_exact, int32_t* nbr_idx, double* nbr_sim, int32_t* nbr_cnt,
                            hipStream_t st);
 void launch_jaccard_pair(const Train& tr, int32_t u, int32_t v, double* d_out, hipStream_t st);
+void launch_sort_neighbors(NeighborTable& nt, int32_t n_rows, const int32_t* d_row_user, hipStream_t st);
 }  // namespace knncf
 
 struct StageTimer {
@@ -178,6 +179,8 @@ void reset_neighbors(knncf_handle* h) {
     size_t cells = (size_t)tr.U * (size_t)std::max(nt.kcap, 1);
     nt.idx.ensure(cells);
     nt.sim.ensure(cells);
+    nt.uidx.ensure(cells);
+    nt.usim.ensure(cells);
     nt.cnt.ensure(tr.U);
     nt.seq.ensure(tr.U);
     KN_HIP(hipMemsetAsync(nt.cnt.p, 0, tr.U * sizeof(int32_t), h->stream));
@@ -249,6 +252,7 @@ void build_neighbors(knncf_handle* h, int32_t count) {
                "kNN neighbourhoods are built for the adjusted-cosine similarity only");
     hipStream_t st = h->stream;
     const bool fp16 = (h->cfg.flags & KNNCF_FLAG_BF16_FILTER) == 0;
+    const bool s_fp16 = (h->cfg.flags & KNNCF_FLAG_F32_PANEL) == 0;  // similarity panel stored as fp16 (half the HBM traffic)
     h->U_pad = round_up(tr.U, 128);
     const int64_t U_pad = h->U_pad;
     size_t free_b = 0, total_b = 0;
@@ -276,7 +280,8 @@ void build_neighbors(knncf_handle* h, int32_t count) {
     for (int s = 0; s < 2; ++s) held += h->S[s].bytes() + h->Apanel[s].bytes();
     int64_t budget = h->cfg.workspace_bytes > 0 ? h->cfg.workspace_bytes / 2
                                                 : (int64_t)std::min<size_t>((size_t)20 << 30, (free_b + held) / 5);
-    int64_t per_row = U_pad * 4 + K_pad * 2;
+    const int64_t s_elem = s_fp16 ? 2 : 4;
+    int64_t per_row = U_pad * s_elem + K_pad * 2;
     int64_t R = std::max<int64_t>(128, (budget / per_row) / 128 * 128);
     R = std::min<int64_t>(R, round_up(count, 128));
     const int64_t n_blocks = ceil_div(count, R);
@@ -286,7 +291,7 @@ void build_neighbors(knncf_handle* h, int32_t count) {
     const bool overlap = (h->cfg.flags & KNNCF_FLAG_OVERLAP) != 0;
     const int slots = (overlap && n_blocks > 1) ? 2 : 1;
     for (int s = 0; s < slots; ++s) {
-        h->S[s].ensure((size_t)R * U_pad);
+        h->S[s].ensure((size_t)(R * U_pad * s_elem + 3) / 4);  // DArr<float> used as raw storage
         h->Apanel[s].ensure((size_t)R * K_pad);
         h->row_of_user[s].ensure(tr.U);
     }
@@ -304,7 +309,8 @@ void build_neighbors(knncf_handle* h, int32_t count) {
         KN_HIP(hipHostMalloc((void**)&h->pinned_cnt, (size_t)count * sizeof(int32_t), hipHostMallocDefault));
         h->pinned_cap = (size_t)count;
     }
-    const float eps = gemm_eps_base(fp16);
+    // fp16 panel storage rounds the dense head once more (|S| <= 1 + eps: <= 2^-11 relative)
+    const float eps = gemm_eps_base(fp16) + (s_fp16 ? 4.9e-4f : 0.f);
     hipStream_t sp = h->stream2;  // producer: densify, GEMM, sparse tail
     hipStream_t sc = h->stream;   // consumer: select, exact re-rank
     KN_HIP(hipEventRecord(h->ev_ready, sc));  // everything queued so far (fit, B panel) precedes the producer
@@ -322,7 +328,7 @@ void build_neighbors(knncf_handle* h, int32_t count) {
         }
         {
             Stage s(h, &h->tm.gemm_ms, sp);
-            launch_gemm_nt(h->Apanel[slot].p, h->Bpanel.p, h->S[slot].p, M, U_pad, K_pad, K_pad, K_pad, U_pad, fp16, sp);
+            launch_gemm_nt(h->Apanel[slot].p, h->Bpanel.p, h->S[slot].p, s_fp16, M, U_pad, K_pad, K_pad, K_pad, U_pad, fp16, sp);
             h->tm.gemm_launches += 1;
             h->tm.gemm_flops_executed += 2.0 * (double)M * (double)U_pad * (double)K_pad;
             // SURVEY 8(d) per-unit figure x the units this launch processes: ordered pairs (row, other user)
@@ -334,7 +340,7 @@ void build_neighbors(knncf_handle* h, int32_t count) {
         {
             // sparse tail (LDS atomics per row tile) + histogram select, fused: one pass over S
             Stage s(h, &h->tm.select_ms, sc);
-            launch_tail_select(tr, h->colmap.p, head < tr.I, h->S[slot].p, U_pad, rows, d_rows, nt.k, eps, cap,
+            launch_tail_select(tr, h->colmap.p, head < tr.I, h->S[slot].p, s_fp16, U_pad, rows, d_rows, nt.k, eps, cap,
                                h->sel.cand_idx.p, h->sel.cand_approx.p, h->sel.cand_cnt.p, sc);
             h->tm.tail_pair_updates += h->tail_pairs_full * ((double)rows / (double)tr.U);
             h->tm.select_row_bytes += 4.0 * (double)rows * (double)tr.U;
@@ -374,6 +380,10 @@ void build_neighbors(knncf_handle* h, int32_t count) {
                                   nt.cnt.p, st);
             h->tm.fallback_rows += 1;
         }
+    }
+    {
+        Stage s(h, &h->tm.rerank_ms);
+        launch_sort_neighbors(nt, count, h->build_list.p, st);
     }
     {
         unsigned long long two[2] = {0, 0};

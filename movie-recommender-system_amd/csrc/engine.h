@@ -50,8 +50,15 @@ struct Train {
     DArr<double> user_avg, user_norm;  // [U]
     DArr<double> item_avg, item_dev_hash, item_dev_file;  // [I]
     // item-major copies for the sparse tail of the hybrid similarity (fp32 is enough: it only filters)
-    DArr<int32_t> it_user;   // [n] dense user of the q-th entry in (item, file) order
-    DArr<float> it_pre;      // [n] preprocessed rating of that entry
+    DArr<int32_t> it_user;   // [n] dense user of the q-th entry in (item, user ascending) order
+    DArr<float> it_pre;      // [n] preprocessed rating of that entry (fp32: the tail only filters)
+    DArr<double> it_dev;     // [n] normalized deviation of that entry (prediction gathers)
+    DArr<uint32_t> it_t;     // [n] training file row of that entry (order of ratedI(i) :508-517)
+    // per-item rater bitmaps over the dense user index + per-word exclusive rank prefixes: "did user x rate
+    // item i, and where is that rating" is one 8-byte read (+ one on a hit) instead of a binary search
+    int64_t ib_words = 0;        // 64-bit words per item row = ceil(U / 64); 0 = not built (too large)
+    DArr<uint64_t> item_bits;    // [I * ib_words]
+    DArr<uint32_t> item_rank;    // [I * ib_words]
     DArr<int32_t> pop_item;  // [I] dense items by descending number of raters
     std::vector<int64_t> pop_count;  // host: rater counts in that order
     double global_avg = 0.0;
@@ -95,7 +102,7 @@ void launch_colmap(const Train& tr, int32_t H, int32_t* d_colmap, hipStream_t st
 // row_of_user[u] = panel row of user u or -1
 void launch_row_of_user(int32_t U, int32_t n_rows, const int32_t* d_rows, int32_t* d_row_of_user, hipStream_t st);
 // C[M][ldc] (fp32) = A[M][K] * B[N][K]^T, bf16 in / fp32 accumulate; M, N multiples of 128, K of 64
-void launch_gemm_nt(const bf16_t* A, const bf16_t* B, float* C, int64_t M, int64_t N, int64_t K,
+void launch_gemm_nt(const bf16_t* A, const bf16_t* B, void* C, bool c_fp16, int64_t M, int64_t N, int64_t K,
                     int64_t lda, int64_t ldb, int64_t ldc, bool fp16, hipStream_t st);
 
 // ---- select.hip: K6 + K6b --------------------------------------------------------------
@@ -104,6 +111,8 @@ struct NeighborTable {
     int32_t kcap = 0;  // min(k, U-1): stored neighbours per user
     DArr<int32_t> idx;   // [U * kcap] dense neighbour ids, reference order
     DArr<double> sim;    // [U * kcap]
+    DArr<int32_t> uidx;  // [U * kcap] the same neighbours sorted by dense id (prediction probes)
+    DArr<double> usim;   // [U * kcap]
     DArr<int32_t> cnt;   // [U] 0 until built
     DArr<int64_t> seq;   // [U] build sequence number (memo history); -1 = not built
 };
@@ -120,7 +129,7 @@ struct SelectScratch {
 
 // per panel row: S[r][:] += sparse tail (items with colmap < 0), then threshold + shortlist:
 // candidates v with S[r][v] >= T_r - 2 eps
-void launch_tail_select(const Train& tr, const int32_t* d_colmap, bool has_tail, float* S, int64_t lds,
+void launch_tail_select(const Train& tr, const int32_t* d_colmap, bool has_tail, const void* S, bool s_fp16, int64_t lds,
                         int32_t n_rows, const int32_t* d_row_user, int32_t k, float eps, int32_t cap,
                         int32_t* cand_idx, float* cand_approx, int32_t* cand_cnt, hipStream_t st);
 // exact fp64 similarities of the shortlists in reference order, stable top-k

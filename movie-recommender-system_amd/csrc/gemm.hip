@@ -149,9 +149,9 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int row, int c
     return *reinterpret_cast<const bf16x8*>(lds_tile + row * 128 + slot * 16);
 }
 
-template <bool F16>
+template <bool F16, class OT>
 __global__ void __launch_bounds__(256, 2)
-k_gemm_nt_bf16(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, float* __restrict__ C, int tiles_m,
+k_gemm_nt_bf16(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, OT* __restrict__ C, int tiles_m,
                int tiles_n, int k_tiles, int64_t lda, int64_t ldb, int64_t ldc) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];  // 2 stages x (A tile + B tile) = 64 KiB
 
@@ -228,7 +228,7 @@ k_gemm_nt_bf16(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, float
     }
 
     // C/D layout of v_mfma_f32_32x32x16: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    float* Cg = C + ((int64_t)tm * BM + wr * 64) * ldc + (int64_t)tn * BN + wc * 64;
+    OT* Cg = C + ((int64_t)tm * BM + wr * 64) * ldc + (int64_t)tn * BN + wc * 64;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -237,25 +237,33 @@ k_gemm_nt_bf16(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, float
             for (int e = 0; e < 16; ++e) {
                 int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
                 int col = j * 32 + frow;
-                Cg[(int64_t)row * ldc + col] = acc[i][j][e];
+                Cg[(int64_t)row * ldc + col] = (OT)acc[i][j][e];
             }
 }
 
-void launch_gemm_nt(const bf16_t* A, const bf16_t* B, float* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+template <bool F16, class OT>
+static void launch_gemm_t(const bf16_t* A, const bf16_t* B, OT* C, int64_t tiles, int64_t M, int64_t N, int64_t K, int64_t lda,
+                          int64_t ldb, int64_t ldc, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        KN_HIP(hipFuncSetAttribute((const void*)k_gemm_nt_bf16<F16, OT>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES));
+        attr_set = true;
+    }
+    k_gemm_nt_bf16<F16, OT><<<(unsigned)tiles, 256, 2 * STAGE_BYTES, st>>>(A, B, C, (int)(M / BM), (int)(N / BN), (int)(K / BK), lda, ldb, ldc);
+    KN_HIP(hipGetLastError());
+}
+
+// C is fp16 (c_fp16) or fp32; operands fp16 (fp16) or bf16
+void launch_gemm_nt(const bf16_t* A, const bf16_t* B, void* C, bool c_fp16, int64_t M, int64_t N, int64_t K, int64_t lda,
                     int64_t ldb, int64_t ldc, bool fp16, hipStream_t st) {
     KN_REQUIRE(M % BM == 0 && N % BN == 0 && K % BK == 0 && K > 0, KNNCF_E_INVALID, "gemm: shape not tile-aligned");
     KN_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, KNNCF_E_INVALID, "gemm: leading dimensions must be multiples of 8");
     int64_t tiles = (M / BM) * (N / BN);
     KN_REQUIRE(tiles > 0 && tiles < (1ll << 31), KNNCF_E_INVALID, "gemm: grid too large");
-    static bool attr_set = false;
-    if (!attr_set) {
-        KN_HIP(hipFuncSetAttribute((const void*)k_gemm_nt_bf16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES));
-        KN_HIP(hipFuncSetAttribute((const void*)k_gemm_nt_bf16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES));
-        attr_set = true;
-    }
-    if (fp16) k_gemm_nt_bf16<true><<<(unsigned)tiles, 256, 2 * STAGE_BYTES, st>>>(A, B, C, (int)(M / BM), (int)(N / BN), (int)(K / BK), lda, ldb, ldc);
-    else k_gemm_nt_bf16<false><<<(unsigned)tiles, 256, 2 * STAGE_BYTES, st>>>(A, B, C, (int)(M / BM), (int)(N / BN), (int)(K / BK), lda, ldb, ldc);
-    KN_HIP(hipGetLastError());
+    if (fp16 && c_fp16) launch_gemm_t<true, _Float16>(A, B, static_cast<_Float16*>(C), tiles, M, N, K, lda, ldb, ldc, st);
+    else if (fp16) launch_gemm_t<true, float>(A, B, static_cast<float*>(C), tiles, M, N, K, lda, ldb, ldc, st);
+    else if (c_fp16) launch_gemm_t<false, _Float16>(A, B, static_cast<_Float16*>(C), tiles, M, N, K, lda, ldb, ldc, st);
+    else launch_gemm_t<false, float>(A, B, static_cast<float*>(C), tiles, M, N, K, lda, ldb, ldc, st);
 }
 
 }  // namespace knncf

@@ -16,6 +16,9 @@
 namespace knncf {
 
 static constexpr int TPB = 256;
+// neighbours probed per lane at once.  Measured: 5 is 15 % SLOWER than 1 — the probes are bound by L2 sector
+// bandwidth (each binary-search step touches its own 64-B sector), not by latency.
+static constexpr int PROBE_ILP = 1;
 
 struct PredArgs {
     const int64_t* u_ptr;
@@ -29,10 +32,19 @@ struct PredArgs {
     double global_avg;
     int32_t own_lo, own_hi;
     // neighbour table
-    const int32_t* nbr_idx;
-    const double* nbr_sim;
+    const int32_t* nbr_uidx;  // neighbour ids sorted ascending
+    const double* nbr_usim;
     const int32_t* nbr_cnt;
     int32_t kcap;
+    // item-major rows, raters ascending
+    const int64_t* i_ptr;
+    const int32_t* it_user;
+    const double* it_dev;
+    const uint32_t* it_t;
+    // per-item rater bitmaps (ib_words == 0: not built, binary search instead)
+    int64_t ib_words;
+    const unsigned long long* item_bits;
+    const uint32_t* item_rank;
 };
 
 __device__ __forceinline__ int64_t find_item(const PredArgs& A, int32_t user, int32_t col) {
@@ -87,20 +99,46 @@ __global__ void __launch_bounds__(WAVES * 64) k_predict_knn(PredArgs A, int64_t 
         const int32_t cnt = A.nbr_cnt[u];
         const int64_t base = (int64_t)u * A.kcap;
         int32_t total = 0;
+        // "which of u's neighbours rated item i": u's neighbour ids (sorted ascending) are looked up in the
+        // item's rater list (sorted the same way).  All lanes search the SAME array and neighbouring lanes
+        // look for neighbouring ids, so the searches share their cache sectors (the per-neighbour-row
+        // searches they replace touched ~7 private sectors each and were bound by L2 sector bandwidth).
+        const int64_t rb = A.i_ptr[i], re = A.i_ptr[i + 1];
         for (int32_t j0 = 0; j0 < cnt; j0 += 64) {
-            int32_t j = j0 + lane;
-            int64_t pos = -1;
+            const int32_t j = j0 + lane;
+            int64_t lo = rb, hi = rb;
+            int32_t x = 0;
             double s = 0.0;
             if (j < cnt) {
-                int32_t v = A.nbr_idx[base + j];
-                s = A.nbr_sim[base + j];
-                pos = find_item(A, v, i);
+                x = A.nbr_uidx[base + j];
+                s = A.nbr_usim[base + j];
+                hi = re;
             }
-            unsigned long long hit = __ballot(pos >= 0);
-            if (pos >= 0) {
-                int32_t slot = total + __popcll(hit & ((1ull << lane) - 1ull));
-                mt[slot] = A.s_t[pos];
-                md[slot] = A.s_dev[pos];
+            bool found;
+            if (A.ib_words > 0) {
+                // rater bitmap of item i (U bits) + rank prefixes: one 8-byte read per neighbour, one more on a hit
+                found = false;
+                if (j < cnt) {
+                    const int64_t w = (int64_t)i * A.ib_words + (x >> 6);
+                    const unsigned long long word = A.item_bits[w];
+                    found = (word >> (x & 63)) & 1ull;
+                    if (found) lo = rb + A.item_rank[w] + __popcll(word & ((1ull << (x & 63)) - 1ull));
+                }
+            } else {
+                while (__any(lo < hi)) {
+                    if (lo < hi) {
+                        const int64_t mid = (lo + hi) >> 1;
+                        if (A.it_user[mid] < x) lo = mid + 1;
+                        else hi = mid;
+                    }
+                }
+                found = j < cnt && lo < re && A.it_user[lo] == x;
+            }
+            const unsigned long long hit = __ballot(found);
+            if (found) {
+                const int32_t slot = total + __popcll(hit & ((1ull << lane) - 1ull));
+                mt[slot] = A.it_t[lo];
+                md[slot] = A.it_dev[lo];
                 ms[slot] = s;
             }
             total += __popcll(hit);
@@ -190,7 +228,9 @@ void launch_predict(const Train& tr, const NeighborTable* nt, int predictor, int
     A.own_lo = tr.own_lo; A.own_hi = tr.own_hi;
     if (predictor == KNNCF_PRED_KNN) {
         KN_REQUIRE(nt != nullptr, KNNCF_E_STATE, "predict: neighbour table missing");
-        A.nbr_idx = nt->idx.p; A.nbr_sim = nt->sim.p; A.nbr_cnt = nt->cnt.p; A.kcap = nt->kcap;
+        A.nbr_uidx = nt->uidx.p; A.nbr_usim = nt->usim.p; A.nbr_cnt = nt->cnt.p; A.kcap = nt->kcap;
+        A.i_ptr = tr.i_ptr.p; A.it_user = tr.it_user.p; A.it_dev = tr.it_dev.p; A.it_t = tr.it_t.p;
+        A.ib_words = tr.ib_words; A.item_bits = reinterpret_cast<const unsigned long long*>(tr.item_bits.p); A.item_rank = tr.item_rank.p;
 #define KN_LAUNCH_KNN(CAPV, WV)                                                                        \
     k_predict_knn<CAPV, WV><<<(unsigned)ceil_div(n, WV), WV * 64, 0, st>>>(                              \
         A, n, d_du, d_di, d_ratings, d_order, d_pred, d_abs_err, d_owned, unknown_users_owned ? 1 : 0)

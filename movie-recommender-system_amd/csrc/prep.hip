@@ -133,35 +133,57 @@ __global__ void k_invert(int64_t n, const uint32_t* __restrict__ s_t, uint32_t* 
 // segment's part of the chunk sequentially.
 static constexpr int FOLD_CHUNK = 2048;
 
+// `spb` consecutive segments per block (<= TPB): the skewed item segments (one item can hold 0.4 % of all
+// ratings) use small groups so that no block serialises several heavy segments; the next chunk's gathers
+// are in flight (registers) while the current chunk is folded out of LDS.
 template <bool SQUARE>
 __global__ void __launch_bounds__(TPB) k_ordered_fold(const int64_t* __restrict__ seg_ptr, int32_t seg_lo,
-                                                      int32_t seg_hi, const uint32_t* __restrict__ perm,
+                                                      int32_t seg_hi, int32_t spb, const uint32_t* __restrict__ perm,
                                                       const double* __restrict__ src, double* __restrict__ out) {
-    __shared__ double buf[FOLD_CHUNK];
-    int32_t s0 = seg_lo + blockIdx.x * TPB;
-    int32_t s1 = min(s0 + TPB, seg_hi);
+    __shared__ double buf[2][FOLD_CHUNK];
+    constexpr int PER = FOLD_CHUNK / TPB;
+    int32_t s0 = seg_lo + blockIdx.x * spb;
+    int32_t s1 = min(s0 + spb, seg_hi);
     if (s0 >= seg_hi) return;
     int32_t s = s0 + threadIdx.x;
+    const bool folder = (int32_t)threadIdx.x < spb && s < s1;
     int64_t e0 = seg_ptr[s0], e1 = seg_ptr[s1];
     int64_t b = 0, e = 0;
-    if (s < s1) {
+    if (folder) {
         b = seg_ptr[s];
         e = seg_ptr[s + 1];
     }
     double acc = 0.0;
-    for (int64_t c = e0; c < e1; c += FOLD_CHUNK) {
-        int32_t len = (int32_t)min((int64_t)FOLD_CHUNK, e1 - c);
-        for (int32_t j = threadIdx.x; j < len; j += TPB) {
-            int64_t idx = perm ? (int64_t)perm[c + j] : (c + j);
-            double v = src[idx];
-            buf[j] = SQUARE ? v * v : v;
+    double r[PER];
+    auto gather = [&](int64_t c) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int64_t i = c + threadIdx.x + (int64_t)j * TPB;
+            r[j] = 0.0;
+            if (i < e1) {
+                const int64_t idx = perm ? (int64_t)perm[i] : i;
+                const double v = src[idx];
+                r[j] = SQUARE ? v * v : v;
+            }
         }
-        __syncthreads();
-        int64_t lo = max(b, c), hi = min(e, c + len);
-        for (int64_t q = lo; q < hi; ++q) acc = acc + buf[q - c];
+    };
+    auto put = [&](int slot) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) buf[slot][threadIdx.x + j * TPB] = r[j];
+    };
+    gather(e0);
+    put(0);
+    __syncthreads();
+    int slot = 0;
+    for (int64_t c = e0; c < e1; c += FOLD_CHUNK, slot ^= 1) {
+        const bool more = c + FOLD_CHUNK < e1;
+        if (more) gather(c + FOLD_CHUNK);  // in flight while this chunk is folded
+        const int64_t lo = max(b, c), hi = min(e, min(e1, c + FOLD_CHUNK));
+        for (int64_t q = lo; q < hi; ++q) acc = acc + buf[slot][q - c];
+        if (more) put(slot ^ 1);
         __syncthreads();
     }
-    if (s < s1) out[s] = acc;
+    if (folder) out[s] = acc;
 }
 
 // whole-array left fold in index order (average :94 when the ratings are not dyadic)
@@ -245,9 +267,9 @@ static int bits_for(uint64_t max_value) {
 
 template <bool SQUARE>
 static void fold(const int64_t* seg_ptr, int32_t lo, int32_t hi, const uint32_t* perm, const double* src,
-                 double* out, hipStream_t st) {
+                 double* out, hipStream_t st, int32_t spb = TPB) {
     if (hi <= lo) return;
-    k_ordered_fold<SQUARE><<<nblocks(hi - lo), TPB, 0, st>>>(seg_ptr, lo, hi, perm, src, out);
+    k_ordered_fold<SQUARE><<<nblocks(hi - lo, spb), TPB, 0, st>>>(seg_ptr, lo, hi, spb, perm, src, out);
     KN_HIP(hipGetLastError());
 }
 
@@ -395,14 +417,50 @@ void prep_fit(Train& tr, PrepScratch& sc, int32_t shard_rank, int32_t shard_coun
                "fit: non-finite normalized deviation (a user's mean is 1 or 5 with a rating beyond it: scale() == 0)");
 }
 
-// item-major (item, file order) copies of (user, preprocessed rating) for the sparse tail
-__global__ void k_item_major(int64_t n, const uint32_t* __restrict__ perm_if, const int32_t* __restrict__ s_user,
-                             const double* __restrict__ s_pre, int32_t* __restrict__ it_user, float* __restrict__ it_pre) {
+// item-major (item, user ascending) copies: (user, preprocessed rating) for the sparse tail of the similarity,
+// (user, deviation, file row) for the prediction's "which neighbours rated item i" probes
+__global__ void k_item_major(int64_t n, const uint32_t* __restrict__ perm_iu, const int32_t* __restrict__ s_user,
+                             const double* __restrict__ s_pre, const double* __restrict__ s_dev,
+                             const uint32_t* __restrict__ s_t, int32_t* __restrict__ it_user, float* __restrict__ it_pre,
+                             double* __restrict__ it_dev, uint32_t* __restrict__ it_t) {
     int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n) return;
-    uint32_t p = perm_if[q];
+    uint32_t p = perm_iu[q];
     it_user[q] = s_user[p];
     it_pre[q] = (float)s_pre[p];
+    it_dev[q] = s_dev[p];
+    it_t[q] = s_t[p];
+}
+
+// rater bitmap of every item: bit v of row i <=> dense user v rated dense item i
+__global__ void k_item_bits(int64_t n, const int32_t* __restrict__ s_user, const int32_t* __restrict__ s_col,
+                            int64_t words, unsigned long long* __restrict__ bits) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int32_t v = s_user[p];
+    atomicOr(&bits[(int64_t)s_col[p] * words + (v >> 6)], 1ull << (v & 63));
+}
+
+// exclusive prefix popcount along each item row (one wave per item)
+__global__ void k_item_rank(int32_t I, int64_t words, const unsigned long long* __restrict__ bits, uint32_t* __restrict__ rank) {
+    const int32_t item = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (item >= I) return;
+    const unsigned long long* b = bits + (int64_t)item * words;
+    uint32_t* r = rank + (int64_t)item * words;
+    uint32_t run = 0;
+    for (int64_t w0 = 0; w0 < words; w0 += 64) {
+        const int64_t w = w0 + lane;
+        const uint32_t c = w < words ? (uint32_t)__popcll(b[w]) : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        if (w < words) r[w] = run + incl - c;
+        run += __shfl(incl, 63);
+    }
 }
 
 __global__ void k_col_keys(int64_t n, const int32_t* __restrict__ s_col, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
@@ -425,13 +483,34 @@ void prep_commit(Train& tr, PrepScratch& sc, hipStream_t st) {
     const int32_t I = tr.I;
     // item-major copies + popularity order (hybrid similarity: dense head / sparse tail)
     // (item, user ascending) order: a stable sort of the user-major positions by item
-    tr.it_user.alloc(n); tr.it_pre.alloc(n); tr.pop_item.alloc(I);
+    tr.it_user.alloc(n); tr.it_pre.alloc(n); tr.it_dev.alloc(n); tr.it_t.alloc(n); tr.pop_item.alloc(I);
     sc.k64_a.ensure(std::max<int64_t>(n, I)); sc.k64_b.ensure(std::max<int64_t>(n, I));
     sc.v32_a.ensure(std::max<int64_t>(n, I)); sc.v32_b.ensure(n);
     k_col_keys<<<nblocks(n), TPB, 0, st>>>(n, tr.s_col.p, sc.k64_a.p, sc.v32_a.p);
     KN_HIP(hipGetLastError());
     sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.v32_a.p, sc.v32_b.p, n, bits_for(I), st);
-    k_item_major<<<nblocks(n), TPB, 0, st>>>(n, sc.v32_b.p, tr.s_user.p, tr.s_pre.p, tr.it_user.p, tr.it_pre.p);
+    k_item_major<<<nblocks(n), TPB, 0, st>>>(n, sc.v32_b.p, tr.s_user.p, tr.s_pre.p, tr.s_dev.p, tr.s_t.p, tr.it_user.p,
+                                             tr.it_pre.p, tr.it_dev.p, tr.it_t.p);
+    // per-item rater bitmaps + rank prefixes for the prediction probes (skipped when they would not fit)
+    {
+        const int64_t words = ceil_div(tr.U, 64);
+        const double bytes = (double)I * (double)words * 12.0;
+        size_t free_b = 0, total_b = 0;
+        KN_HIP(hipMemGetInfo(&free_b, &total_b));
+        if (bytes < 0.15 * (double)(free_b + tr.item_bits.bytes() + tr.item_rank.bytes())) {
+            tr.ib_words = words;
+            tr.item_bits.ensure((size_t)I * words);
+            tr.item_rank.ensure((size_t)I * words);
+            KN_HIP(hipMemsetAsync(tr.item_bits.p, 0, (size_t)I * words * sizeof(uint64_t), st));
+            k_item_bits<<<nblocks(n), TPB, 0, st>>>(n, tr.s_user.p, tr.s_col.p, words,
+                                                    reinterpret_cast<unsigned long long*>(tr.item_bits.p));
+            k_item_rank<<<nblocks((int64_t)I * 64), TPB, 0, st>>>(I, words, reinterpret_cast<const unsigned long long*>(tr.item_bits.p),
+                                                                  tr.item_rank.p);
+            KN_HIP(hipGetLastError());
+        } else {
+            tr.ib_words = 0;
+        }
+    }
     k_pop_keys<<<nblocks(I), TPB, 0, st>>>(I, tr.i_ptr.p, sc.k64_a.p, sc.v32_a.p);
     KN_HIP(hipGetLastError());
     sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.v32_a.p, reinterpret_cast<uint32_t*>(tr.pop_item.p), I, 64, st);
@@ -445,13 +524,13 @@ void prep_commit(Train& tr, PrepScratch& sc, hipStream_t st) {
     tr.item_avg.alloc(I); tr.item_dev_hash.alloc(I); tr.item_dev_file.alloc(I);
     sc.dsum.ensure((size_t)I + 2);
     // itemsAvg :134
-    fold<false>(tr.i_ptr.p, 0, I, tr.perm_if.p, tr.s_rating.p, sc.dsum.p, st);
+    fold<false>(tr.i_ptr.p, 0, I, tr.perm_if.p, tr.s_rating.p, sc.dsum.p, st, 16);
     k_divide_by_count<<<nblocks(I), TPB, 0, st>>>(tr.i_ptr.p, 0, I, sc.dsum.p, tr.item_avg.p);
     // getItemsAvgDev :336-343 (reduceByKey, modelled in file order)
-    fold<false>(tr.i_ptr.p, 0, I, tr.perm_if.p, tr.s_dev.p, sc.dsum.p, st);
+    fold<false>(tr.i_ptr.p, 0, I, tr.perm_if.p, tr.s_dev.p, sc.dsum.p, st, 16);
     k_divide_by_count<<<nblocks(I), TPB, 0, st>>>(tr.i_ptr.p, 0, I, sc.dsum.p, tr.item_dev_file.p);
     // itemsAvgDev :176-186 (foldLeft over the HashMap: trie order of the (user,item) hashes)
-    fold<false>(tr.i_ptr.p, 0, I, n > 4 ? tr.perm_ih.p : tr.perm_if.p, tr.s_dev.p, sc.dsum.p, st);
+    fold<false>(tr.i_ptr.p, 0, I, n > 4 ? tr.perm_ih.p : tr.perm_if.p, tr.s_dev.p, sc.dsum.p, st, 16);
     k_divide_by_count<<<nblocks(I), TPB, 0, st>>>(tr.i_ptr.p, 0, I, sc.dsum.p, tr.item_dev_hash.p);
     KN_HIP(hipGetLastError());
 }

@@ -1,21 +1,21 @@
 // select.hip — K5 sparse tail + K6 top-k neighbour select, fused per similarity row.
 //
-// The dense MFMA GEMM (gemm.hip) leaves S[u][v] = sum over the H most-rated items.  For row u this
-// kernel (one 1024-thread workgroup per row) walks the row ONCE, a column tile (20 480 columns =
-// 80 KiB of LDS) at a time:
+// The dense MFMA GEMM (gemm.hip) leaves S[u][v] = sum over the H most-rated items (fp16 or fp32
+// storage).  For row u this kernel (one 1024-thread workgroup per row) walks the row ONCE, a column tile
+// (24 576 columns = 96 KiB of LDS) at a time:
 //   1. SPARSE TAIL: for every tail item i rated by u and every rater v of i inside the tile,
-//      pre(u,i) * pre(v,i) is accumulated with LDS float atomics (the rater lists are sorted by user,
-//      so each list is swept once across the tiles with a per-entry cursor kept in LDS);
-//   2. the tile's final values S + tail stay in LDS and enter a cumulative 4096-bin histogram; the
-//      bin holding the k-th largest value SEEN SO FAR gives a threshold that can only rise as more
-//      columns are seen, so every v of the tile with value >= (bin lower edge - 2 eps) is appended to
-//      a provisional shortlist straight from LDS;
+//      pre(u,i) * pre(v,i) is accumulated in Q7.24 fixed point with integer LDS atomics (the rater lists
+//      are sorted by user, so each list is swept once across the tiles with a per-entry cursor kept in
+//      LDS; rows with more than EMAX ratings re-derive their cursors per tile by binary search);
+//   2. the tile's final values S + tail stay in registers and enter a cumulative 4096-bin LDS histogram;
+//      the bin holding the k-th largest value SEEN SO FAR gives a threshold that can only rise as more
+//      columns are seen, so every v of the tile with value >= (bin lower edge - 2 eps) is appended to a
+//      provisional shortlist;
 //   3. after the last tile the threshold is final and the provisional list is compacted in place.
 // With |S[u][v] - s_uv| <= eps for every pair, every true top-k member v satisfies
 // S[u][v] >= a_k - 2 eps (a_k = k-th largest value of the row), so the shortlist provably contains
-// the exact top-k; rerank.hip decides.  HBM-bound: S is read exactly once and never written back
-// (rows with > EMAX ratings take extra read-modify-write sweeps); the tail's per-pair products never
-// touch HBM atomics.
+// the exact top-k; rerank.hip decides.  HBM-bound: S is read exactly once and never written back; the
+// tail's per-pair products never touch HBM atomics.
 #include <math.h>
 #include <stdlib.h>
 
@@ -25,13 +25,14 @@ namespace knncf {
 
 static constexpr int TPB = 1024;
 static constexpr int NBINS = 4096;
-static constexpr int TCOLS = 20480;  // columns of the row held in LDS at a time (80 KiB)
+static constexpr int TCOLS = 24576;  // columns of the row held in LDS at a time (96 KiB)
+static constexpr int CPT = TCOLS / TPB;  // columns per thread per tile (24 = 3 groups of 8)
 static constexpr int EMAX = 2048;    // row positions whose tail cursors are held in LDS at a time
 static constexpr int MAX_PER_THREAD = 16;  // provisional entries per thread in the final compaction
 static constexpr int TAIL_ILP = 4;         // tail entries a wave keeps in flight
 static constexpr int TAIL_CH = 2;          // 64-rater pieces requested ahead per entry
 // the tail is accumulated in Q7.24 fixed point with integer LDS atomics (ds_add_u32; the float form
-// ds_add_f32 measured ~10x slower here): |sum| <= 1, each product is quantised with error <= 2^-25,
+// ds_add_f32 measured ~1.4x slower here): |sum| <= 1, each product is quantised with error <= 2^-25,
 // which the per-common-item term of row_eps covers
 static constexpr float TAIL_FIX = 16777216.0f;
 static constexpr float TAIL_UNFIX = 1.0f / 16777216.0f;
@@ -99,14 +100,26 @@ __device__ __forceinline__ void block_threshold(const uint32_t* hist, uint32_t* 
     __syncthreads();
 }
 
-__global__ void __launch_bounds__(TPB) k_tail_select(float* __restrict__ S, int64_t ld, int32_t n_rows,
+// 8 consecutive panel entries starting at a multiple of 8 (rows are padded to ld, a multiple of 128)
+__device__ __forceinline__ void load8(const float* p, float* out) {
+    const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+    out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w; out[4] = b.x; out[5] = b.y; out[6] = b.z; out[7] = b.w;
+}
+__device__ __forceinline__ void load8(const _Float16* p, float* out) {
+    typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+    const h8 v = *reinterpret_cast<const h8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = (float)v[i];
+}
+
+template <class ST>
+__global__ void __launch_bounds__(TPB) k_tail_select(const ST* __restrict__ S, int64_t ld, int32_t n_rows,
                                                      const int32_t* __restrict__ row_user, TailArgs T, int32_t U,
                                                      int32_t kk, float eps_base, int32_t cap, int32_t* __restrict__ cand_idx,
                                                      float* __restrict__ cand_approx, int32_t* __restrict__ cand_cnt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* tile = reinterpret_cast<float*>(smem);                // [TCOLS]
-    int32_t* itile = reinterpret_cast<int32_t*>(smem);            // the same tile while it accumulates the tail
-    uint32_t* hist = reinterpret_cast<uint32_t*>(tile + TCOLS);   // [NBINS]
+    int32_t* itile = reinterpret_cast<int32_t*>(smem);            // [TCOLS] tail accumulator, Q7.24
+    uint32_t* hist = reinterpret_cast<uint32_t*>(itile + TCOLS);  // [NBINS]
     int64_t* e_cur = reinterpret_cast<int64_t*>(hist + NBINS);    // [EMAX] cursor into it_user / it_pre
     int64_t* e_end = e_cur + EMAX;                                // [EMAX]
     float* e_x = reinterpret_cast<float*>(e_end + EMAX);          // [EMAX] pre(u, item)
@@ -120,51 +133,74 @@ __global__ void __launch_bounds__(TPB) k_tail_select(float* __restrict__ S, int6
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t ub = T.u_ptr[u], ue = T.u_ptr[u + 1];
     const float eps = row_eps(eps_base, ue - ub);
-    float* row = S + (int64_t)r * ld;
+    const ST* row = S + (int64_t)r * ld;
     int32_t* out_idx = cand_idx + (int64_t)r * cap;
     float* out_apx = cand_approx + (int64_t)r * cap;
     for (int b = threadIdx.x; b < NBINS; b += TPB) hist[b] = 0;
-    if (threadIdx.x == 0) s_count = 0;
+    if (threadIdx.x == 0) { s_count = 0; s_ne = 0; }
+    __syncthreads();
 
-    // the row is taken EMAX positions at a time (one chunk for all but the heaviest raters); every chunk
-    // sweeps the column tiles once; the last one selects, earlier ones only add their tail part to S
-    int64_t cb = ub;
-    bool last_chunk;
-    do {
-        const int64_t ce = min(ue, cb + EMAX);
-        last_chunk = ce >= ue;
-        __syncthreads();
-        if (threadIdx.x == 0) s_ne = 0;
-        __syncthreads();
-        if (T.has_tail) {
-            for (int64_t p = cb + threadIdx.x; p < ce; p += TPB) {
-                const int32_t item = T.s_col[p];
-                if (T.colmap[item] < 0) {
-                    const int32_t slot = atomicAdd(&s_ne, 1);
-                    e_cur[slot] = T.i_ptr[item];
-                    e_end[slot] = T.i_ptr[item + 1];
-                    e_x[slot] = (float)T.s_pre[p];
-                }
+    // tail entries of the row.  Rows of up to EMAX ratings (all but the heaviest raters) collect them once and
+    // keep one cursor per entry in LDS across the tiles; longer rows take EMAX positions at a time and
+    // re-derive the cursors of every chunk for every tile by binary search.
+    const bool single = (ue - ub) <= EMAX;
+    const int n_chunks = T.has_tail ? (int)((ue - ub + EMAX - 1) / EMAX) : 0;
+    if (single && n_chunks > 0) {
+        for (int64_t p = ub + threadIdx.x; p < ue; p += TPB) {
+            const int32_t item = T.s_col[p];
+            if (T.colmap[item] < 0) {
+                const int32_t slot = atomicAdd(&s_ne, 1);
+                e_cur[slot] = T.i_ptr[item];
+                e_end[slot] = T.i_ptr[item + 1];
+                e_x[slot] = (float)T.s_pre[p];
             }
         }
         __syncthreads();
-        const int32_t ne = s_ne;
-        for (int32_t t0 = 0; t0 < U; t0 += TCOLS) {
-            const int32_t t1 = min(U, t0 + TCOLS);
-            // this thread's 20 columns of the tile: float4 j covers columns t0 + 4 (tid + 1024 j) .. + 3.
-            // S rows are padded to ld (a multiple of 128) with zeros, so whole float4s can be read; the
-            // loads are issued first so that their HBM latency hides behind the tail accumulation
-            float4 sx[TCOLS / (4 * TPB)];
-            if (last_chunk) {
+    }
+    const bool any_tail = n_chunks > 0 && (!single || s_ne > 0);
+
+    for (int32_t t0 = 0; t0 < U; t0 += TCOLS) {
+        const int32_t t1 = min(U, t0 + TCOLS);
+        // this thread's 24 columns of the tile: group j covers columns t0 + 8 (tid + 1024 j) .. + 7.  The loads
+        // are issued first so that their HBM latency hides behind the tail accumulation
+        float sx[CPT];
 #pragma unroll
-                for (int j = 0; j < TCOLS / (4 * TPB); ++j) {
-                    const int64_t v0 = (int64_t)t0 + 4 * (threadIdx.x + TPB * j);
-                    sx[j] = (v0 < ld) ? *reinterpret_cast<const float4*>(row + v0) : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+        for (int j = 0; j < CPT / 8; ++j) {
+            const int64_t v0 = (int64_t)t0 + 8 * (threadIdx.x + TPB * j);
+            if (v0 < ld) load8(row + v0, &sx[8 * j]);
+            else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sx[8 * j + i] = 0.f;
             }
-            if (ne > 0) {
-                for (int32_t c = threadIdx.x; c < t1 - t0; c += TPB) itile[c] = 0;
-                __syncthreads();
+        }
+        if (any_tail) {
+            for (int32_t c = threadIdx.x; c < t1 - t0; c += TPB) itile[c] = 0;
+            __syncthreads();
+            for (int ch = 0; ch < n_chunks; ++ch) {
+                if (!single) {  // collect this chunk's entries with cursors at the tile's first column
+                    __syncthreads();
+                    if (threadIdx.x == 0) s_ne = 0;
+                    __syncthreads();
+                    const int64_t cb = ub + (int64_t)ch * EMAX, ce = min(ue, cb + EMAX);
+                    for (int64_t p = cb + threadIdx.x; p < ce; p += TPB) {
+                        const int32_t item = T.s_col[p];
+                        if (T.colmap[item] < 0) {
+                            int64_t lo = T.i_ptr[item], hi = T.i_ptr[item + 1];
+                            const int64_t end = hi;
+                            while (lo < hi) {
+                                const int64_t mid = (lo + hi) >> 1;
+                                if (T.it_user[mid] < t0) lo = mid + 1;
+                                else hi = mid;
+                            }
+                            const int32_t slot = atomicAdd(&s_ne, 1);
+                            e_cur[slot] = lo;
+                            e_end[slot] = end;
+                            e_x[slot] = (float)T.s_pre[p];
+                        }
+                    }
+                    __syncthreads();
+                }
+                const int32_t ne = s_ne;
                 // one wave per tail entry; TAIL_ILP entries x TAIL_CH 64-rater pieces are requested before any
                 // is consumed (the loop is latency-bound: rater lists are short and come from L2/HBM)
                 for (int32_t e0 = wave; e0 < ne; e0 += TAIL_ILP * (TPB / 64)) {
@@ -213,82 +249,71 @@ __global__ void __launch_bounds__(TPB) k_tail_select(float* __restrict__ S, int6
                             any_live = any_live || live[j];
                         }
                     }
+                    if (single) {
 #pragma unroll
-                    for (int j = 0; j < TAIL_ILP; ++j) {
-                        const int32_t e = e0 + j * (TPB / 64);
-                        if (e < ne && lane == 0) e_cur[e] = q[j];
+                        for (int j = 0; j < TAIL_ILP; ++j) {
+                            const int32_t e = e0 + j * (TPB / 64);
+                            if (e < ne && lane == 0) e_cur[e] = q[j];
+                        }
                     }
                 }
                 __syncthreads();
             }
-            if (!last_chunk) {
-                if (ne > 0) {  // S += this chunk's tail part
-                    for (int32_t c = threadIdx.x; c < t1 - t0; c += TPB) row[t0 + c] += (float)itile[c] * TAIL_UNFIX;
-                    __syncthreads();
-                }
-                continue;
-            }
             // final values of this thread's columns (registers)
-            if (ne > 0) {
 #pragma unroll
-                for (int j = 0; j < TCOLS / (4 * TPB); ++j) {
-                    const int32_t c = 4 * (threadIdx.x + TPB * j);
-                    if (c < t1 - t0) {  // (t1 - t0 is a multiple of 4 except for the last tile: guard per element below)
-                        sx[j].x += (float)itile[c] * TAIL_UNFIX;
-                        if (c + 1 < t1 - t0) sx[j].y += (float)itile[c + 1] * TAIL_UNFIX;
-                        if (c + 2 < t1 - t0) sx[j].z += (float)itile[c + 2] * TAIL_UNFIX;
-                        if (c + 3 < t1 - t0) sx[j].w += (float)itile[c + 3] * TAIL_UNFIX;
-                    }
-                }
+            for (int j = 0; j < CPT / 8; ++j) {
+                const int32_t c0 = 8 * (threadIdx.x + TPB * j);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (c0 + i < t1 - t0) sx[8 * j + i] += (float)itile[c0 + i] * TAIL_UNFIX;
             }
-            // cumulative histogram.  Only values >= the current threshold can matter for the k-th largest
-            // (the threshold never exceeds it), which also keeps the LDS atomics off the crowded bins near 0.
-            // First tile: a 1/8 subsample bootstraps a valid threshold (the k-th largest of a subset is a
-            // lower bound of the k-th largest of the row).
-            float floor_thr = (t0 == 0) ? -INFINITY : s_thr;
-            for (int pass = (t0 == 0 ? 0 : 1); pass < 2; ++pass) {
-                const bool mine = (t0 != 0) || (((threadIdx.x & 7) == 0) == (pass == 0));
-                if (mine) {
-#pragma unroll
-                    for (int j = 0; j < TCOLS / (4 * TPB); ++j) {
-                        const int32_t v0 = t0 + 4 * (threadIdx.x + TPB * j);
-                        const float xs[4] = {sx[j].x, sx[j].y, sx[j].z, sx[j].w};
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int32_t v = v0 + i;
-                            if (v < t1 && v != u && xs[i] >= floor_thr) atomicAdd(&hist[sim_bin(xs[i])], 1u);
-                        }
-                    }
-                }
-                if (t0 == 0 && pass == 0) {
-                    __syncthreads();
-                    block_threshold(hist, wtot, &s_thr, kk, eps);
-                    floor_thr = s_thr;
-                }
-            }
-            __syncthreads();
-            block_threshold(hist, wtot, &s_thr, kk, eps);
-            const float thr = s_thr;  // valid for every column seen so far; it can only rise later
-#pragma unroll
-            for (int j = 0; j < TCOLS / (4 * TPB); ++j) {
-                const int32_t v0 = t0 + 4 * (threadIdx.x + TPB * j);
-                const float xs[4] = {sx[j].x, sx[j].y, sx[j].z, sx[j].w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int32_t v = v0 + i;
-                    if (v < t1 && v != u && xs[i] >= thr) {
-                        const uint32_t pos = atomicAdd(&s_count, 1u);
-                        if (pos < (uint32_t)cap) {
-                            out_idx[pos] = v;
-                            out_apx[pos] = xs[i];
-                        }
-                    }
-                }
-            }
-            __syncthreads();
         }
-        cb = ce;
-    } while (!last_chunk);
+        // cumulative histogram.  Only values >= the current threshold can matter for the k-th largest
+        // (the threshold never exceeds it), which also keeps the LDS atomics off the crowded bins near 0.
+        // First tile: a 1/8 subsample bootstraps a valid threshold (the k-th largest of a subset is a
+        // lower bound of the k-th largest of the row).
+        float floor_thr = (t0 == 0) ? -INFINITY : s_thr;
+        for (int pass = (t0 == 0 ? 0 : 1); pass < 2; ++pass) {
+            const bool mine = (t0 != 0) || (((threadIdx.x & 7) == 0) == (pass == 0));
+            if (mine) {
+#pragma unroll
+                for (int j = 0; j < CPT / 8; ++j) {
+                    const int32_t v0 = t0 + 8 * (threadIdx.x + TPB * j);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int32_t v = v0 + i;
+                        const float x = sx[8 * j + i];
+                        if (v < t1 && v != u && x >= floor_thr) atomicAdd(&hist[sim_bin(x)], 1u);
+                    }
+                }
+            }
+            if (t0 == 0 && pass == 0) {
+                __syncthreads();
+                block_threshold(hist, wtot, &s_thr, kk, eps);
+                floor_thr = s_thr;
+            }
+        }
+        __syncthreads();
+        block_threshold(hist, wtot, &s_thr, kk, eps);
+        const float thr = s_thr;  // valid for every column seen so far; it can only rise later
+#pragma unroll
+        for (int j = 0; j < CPT / 8; ++j) {
+            const int32_t v0 = t0 + 8 * (threadIdx.x + TPB * j);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int32_t v = v0 + i;
+                const float x = sx[8 * j + i];
+                if (v < t1 && v != u && x >= thr) {
+                    const uint32_t pos = atomicAdd(&s_count, 1u);
+                    if (pos < (uint32_t)cap) {
+                        out_idx[pos] = v;
+                        out_apx[pos] = x;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
 
     // ---- compaction of the provisional list by the final threshold (in place) ------------------------
     const uint32_t prov = s_count;
@@ -324,7 +349,21 @@ __global__ void __launch_bounds__(TPB) k_tail_select(float* __restrict__ S, int6
     if (threadIdx.x == 0) cand_cnt[r] = (int32_t)s_count;
 }
 
-void launch_tail_select(const Train& tr, const int32_t* d_colmap, bool has_tail, float* S, int64_t lds,
+template <class ST>
+static void launch_tail_select_t(const TailArgs& T, const ST* S, int64_t lds, int32_t n_rows, const int32_t* d_row_user,
+                                 int32_t U, int32_t kk, float eps, int32_t cap, int32_t* cand_idx, float* cand_approx,
+                                 int32_t* cand_cnt, hipStream_t st) {
+    const size_t smem = (size_t)TCOLS * 4 + (size_t)NBINS * 4 + (size_t)EMAX * (8 + 8 + 4);
+    static bool attr_set = false;
+    if (!attr_set) {
+        KN_HIP(hipFuncSetAttribute((const void*)k_tail_select<ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    k_tail_select<ST><<<n_rows, TPB, smem, st>>>(S, lds, n_rows, d_row_user, T, U, kk, eps, cap, cand_idx, cand_approx, cand_cnt);
+    KN_HIP(hipGetLastError());
+}
+
+void launch_tail_select(const Train& tr, const int32_t* d_colmap, bool has_tail, const void* S, bool s_fp16, int64_t lds,
                         int32_t n_rows, const int32_t* d_row_user, int32_t k, float eps, int32_t cap,
                         int32_t* cand_idx, float* cand_approx, int32_t* cand_cnt, hipStream_t st) {
     if (n_rows <= 0) return;
@@ -332,16 +371,9 @@ void launch_tail_select(const Train& tr, const int32_t* d_colmap, bool has_tail,
     const int32_t U = tr.U;
     int32_t kk = k < U - 1 ? k : U - 1;
     if (kk < 1) kk = 1;
-    if (getenv("KNNCF_DEBUG_NO_TAIL")) has_tail = false;  // TIMING EXPERIMENT ONLY (wrong results)
     TailArgs T{tr.u_ptr.p, tr.s_col.p, tr.s_pre.p, d_colmap, tr.i_ptr.p, tr.it_user.p, tr.it_pre.p, has_tail ? 1 : 0};
-    const size_t smem = (size_t)TCOLS * 4 + (size_t)NBINS * 4 + (size_t)EMAX * (8 + 8 + 4);
-    static bool attr_set = false;
-    if (!attr_set) {
-        KN_HIP(hipFuncSetAttribute((const void*)k_tail_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
-    }
-    k_tail_select<<<n_rows, TPB, smem, st>>>(S, lds, n_rows, d_row_user, T, U, kk, eps, cap, cand_idx, cand_approx, cand_cnt);
-    KN_HIP(hipGetLastError());
+    if (s_fp16) launch_tail_select_t(T, static_cast<const _Float16*>(S), lds, n_rows, d_row_user, U, kk, eps, cap, cand_idx, cand_approx, cand_cnt, st);
+    else launch_tail_select_t(T, static_cast<const float*>(S), lds, n_rows, d_row_user, U, kk, eps, cap, cand_idx, cand_approx, cand_cnt, st);
 }
 
 }  // namespace knncf

@@ -19,6 +19,7 @@ PRED_GLOBAL_AVG, PRED_USER_AVG, PRED_ITEM_AVG, PRED_BASELINE, PRED_BASELINE_RDD,
 FLAG_VERIFY_BOUND = 1
 FLAG_OVERLAP = 2
 FLAG_BF16_FILTER = 4  # default filter operand type is fp16 (narrower error band, same MFMA rate)
+FLAG_F32_PANEL = 8    # default similarity panel storage is fp16
 HEAD_ALL = 0xFFFFFFFF
 
 _i32p = C.POINTER(C.c_int32)
