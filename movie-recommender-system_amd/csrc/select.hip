@@ -23,6 +23,9 @@
 
 namespace knncf {
 
+// One 1024-thread workgroup per CU with the largest tile that fits.  Measured alternative: two 512-thread
+// workgroups per CU with 48 KiB tiles (twice as many tiles per row) ran 1.7x SLOWER — the cost is per tile
+// (barrier-separated phases), so fewer, larger tiles win.
 static constexpr int TPB = 1024;
 static constexpr int NBINS = 4096;
 static constexpr int TCOLS = 24576;  // columns of the row held in LDS at a time (96 KiB)
@@ -158,8 +161,13 @@ __global__ void __launch_bounds__(TPB) k_tail_select(const ST* __restrict__ S, i
         __syncthreads();
     }
     const bool any_tail = n_chunks > 0 && (!single || s_ne > 0);
+    if (any_tail) {  // the accumulator starts clean; afterwards every tile's read-out clears what it reads
+        for (int32_t c = threadIdx.x; c < TCOLS; c += TPB) itile[c] = 0;
+        __syncthreads();
+    }
 
-    for (int32_t t0 = 0; t0 < U; t0 += TCOLS) {
+    int tile_no = 0;
+    for (int32_t t0 = 0; t0 < U; t0 += TCOLS, ++tile_no) {
         const int32_t t1 = min(U, t0 + TCOLS);
         // this thread's 24 columns of the tile: group j covers columns t0 + 8 (tid + 1024 j) .. + 7.  The loads
         // are issued first so that their HBM latency hides behind the tail accumulation
@@ -174,8 +182,6 @@ __global__ void __launch_bounds__(TPB) k_tail_select(const ST* __restrict__ S, i
             }
         }
         if (any_tail) {
-            for (int32_t c = threadIdx.x; c < t1 - t0; c += TPB) itile[c] = 0;
-            __syncthreads();
             for (int ch = 0; ch < n_chunks; ++ch) {
                 if (!single) {  // collect this chunk's entries with cursors at the tile's first column
                     __syncthreads();
@@ -265,7 +271,10 @@ __global__ void __launch_bounds__(TPB) k_tail_select(const ST* __restrict__ S, i
                 const int32_t c0 = 8 * (threadIdx.x + TPB * j);
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
-                    if (c0 + i < t1 - t0) sx[8 * j + i] += (float)itile[c0 + i] * TAIL_UNFIX;
+                    if (c0 + i < t1 - t0) {
+                        sx[8 * j + i] += (float)itile[c0 + i] * TAIL_UNFIX;
+                        itile[c0 + i] = 0;  // clean for the next tile (only this thread touches these cells here)
+                    }
             }
         }
         // cumulative histogram.  Only values >= the current threshold can matter for the k-th largest
@@ -293,9 +302,13 @@ __global__ void __launch_bounds__(TPB) k_tail_select(const ST* __restrict__ S, i
                 floor_thr = s_thr;
             }
         }
-        __syncthreads();
-        block_threshold(hist, wtot, &s_thr, kk, eps);
-        const float thr = s_thr;  // valid for every column seen so far; it can only rise later
+        // The threshold is refreshed after the first tiles only (it can only rise; a stale one just lets a few
+        // more provisional entries through) — every refresh costs three workgroup barriers.
+        if (tile_no <= 1 || tile_no == 3) {
+            __syncthreads();
+            block_threshold(hist, wtot, &s_thr, kk, eps);
+        }
+        const float thr = s_thr;  // valid for every column seen so far
 #pragma unroll
         for (int j = 0; j < CPT / 8; ++j) {
             const int32_t v0 = t0 + 8 * (threadIdx.x + TPB * j);
@@ -321,6 +334,7 @@ __global__ void __launch_bounds__(TPB) k_tail_select(const ST* __restrict__ S, i
         if (threadIdx.x == 0) cand_cnt[r] = (int32_t)min(prov, (uint32_t)0x7fffffff);
         return;
     }
+    block_threshold(hist, wtot, &s_thr, kk, eps);  // final: the whole row is in the histogram
     const float thr = s_thr;
     int32_t kv[MAX_PER_THREAD];
     float kx[MAX_PER_THREAD];
