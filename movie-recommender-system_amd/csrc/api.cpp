@@ -229,7 +229,7 @@ int32_t choose_head(knncf_handle* h, int32_t rows_total) {
         const double RATE_DENSE = 1.1e15;   // marginal flop/s of k_gemm_nt_bf16 per extra dense column (measured)
         const double RATE_SPARSE = 3.0e11;  // marginal tail pair products per second through LDS atomics (k_tail_select, measured)
         const double frac = (double)rows_total / (double)tr.U;
-        const double U_pad = (double)round_up(tr.U, 128);
+        const double U_pad = (double)round_up(tr.U, 256);
         double best = 1e300;
         H = I;
         for (int64_t cand = 64;; cand += 64) {
@@ -253,7 +253,7 @@ void build_neighbors(knncf_handle* h, int32_t count) {
     hipStream_t st = h->stream;
     const bool fp16 = (h->cfg.flags & KNNCF_FLAG_BF16_FILTER) == 0;
     const bool s_fp16 = (h->cfg.flags & KNNCF_FLAG_F32_PANEL) == 0;  // similarity panel stored as fp16 (half the HBM traffic)
-    h->U_pad = round_up(tr.U, 128);
+    h->U_pad = round_up(tr.U, 256);
     const int64_t U_pad = h->U_pad;
     size_t free_b = 0, total_b = 0;
     KN_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -282,10 +282,10 @@ void build_neighbors(knncf_handle* h, int32_t count) {
                                                 : (int64_t)std::min<size_t>((size_t)20 << 30, (free_b + held) / 5);
     const int64_t s_elem = s_fp16 ? 2 : 4;
     int64_t per_row = U_pad * s_elem + K_pad * 2;
-    int64_t R = std::max<int64_t>(128, (budget / per_row) / 128 * 128);
-    R = std::min<int64_t>(R, round_up(count, 128));
+    int64_t R = std::max<int64_t>(256, (budget / per_row) / 256 * 256);
+    R = std::min<int64_t>(R, round_up(count, 256));
     const int64_t n_blocks = ceil_div(count, R);
-    R = round_up(ceil_div(count, n_blocks), 128);  // equal blocks: no short straggler at the end
+    R = round_up(ceil_div(count, n_blocks), 256);  // equal blocks: no short straggler at the end
     // KNNCF_FLAG_OVERLAP: run the producer one block ahead.  Measured on MI355X (ml-25m shape): -5 % step
     // time, but GEMM and re-rank then contend for LDS/CUs (GEMM 890 -> 506 TFLOP/s), so it is opt-in.
     const bool overlap = (h->cfg.flags & KNNCF_FLAG_OVERLAP) != 0;
@@ -318,7 +318,7 @@ void build_neighbors(knncf_handle* h, int32_t count) {
     for (int64_t b = 0; b < n_blocks; ++b) {
         const int64_t rb = b * R;
         const int32_t rows = (int32_t)std::min<int64_t>(R, count - rb);
-        const int64_t M = round_up(rows, 128);
+        const int64_t M = round_up(rows, 256);
         const int32_t* d_rows = h->build_list.p + rb;
         const int slot = (int)(b % slots);
         if (b >= slots) KN_HIP(hipStreamWaitEvent(sp, h->ev_consumed[slot], 0));  // S[slot] has been read

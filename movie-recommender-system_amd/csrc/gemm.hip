@@ -13,6 +13,8 @@
 // SOURCE address (16-B chunk c of row r sits in slot c ^ ((r >> 1) & 7), conflict-free for
 // ds_read_b128: the 16 lanes of a read group hit 16 distinct slots of the 256-B bank row).
 // Tile t+1 stays in flight across the barrier behind a counted vmcnt.
+#include <stdlib.h>
+
 #include "engine.h"
 
 namespace knncf {
@@ -126,16 +128,25 @@ void launch_row_of_user(int32_t U, int32_t n_rows, const int32_t* d_rows, int32_
 }
 
 // ---- GEMM --------------------------------------------------------------------------------
-static constexpr int BM = 128, BN = 128, BK = 64;
-static constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand tile
-static constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // A + B
-static constexpr int LOADS_PER_TILE = TILE_BYTES / 1024 / 4;  // wave-instructions per wave per operand tile = 4
+// Tile configurations (BK = 64 for both; a wave always owns a WM*32 x 64 sub-tile):
+//   small: 128 x 128, 4 waves (2 x 2), WM = 2, 64 KiB LDS, 2 workgroups per CU
+//   large: 256 x 256, 8 waves (2 x 4), WM = 4, 128 KiB LDS, 1 workgroup per CU — half the L2 -> LDS operand
+//          traffic per flop (at the MFMA peak the 128 x 128 tile asks the L2 for ~39 TB/s, more than it has)
+static constexpr int BK = 64;
 
-// issue this wave's share of one operand tile (128 rows x 64 bf16) into LDS
+template <int ROWS>
+struct TileGeom {
+    static constexpr int TILE_BYTES = ROWS * BK * 2;       // one operand tile: ROWS x 64 16-bit elements
+    static constexpr int STAGE_BYTES = 2 * TILE_BYTES;     // A + B
+};
+
+// issue this wave's share of one operand tile (ROWS rows x 64 elements) into LDS: 1-KiB pieces of 8 rows
+template <int ROWS, int WAVES>
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int64_t ld, char* lds_tile, int wave, int lane) {
+    constexpr int LOADS = ROWS / 8 / WAVES;
 #pragma unroll
-    for (int j = 0; j < LOADS_PER_TILE; ++j) {
-        int piece = wave * LOADS_PER_TILE + j;       // 1-KiB piece = 8 rows of the tile
+    for (int j = 0; j < LOADS; ++j) {
+        int piece = wave * LOADS + j;
         int row = piece * 8 + (lane >> 3);
         int slot = lane & 7;
         int chunk = slot ^ ((row >> 1) & 7);         // swizzle on the source side
@@ -149,11 +160,22 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int row, int c
     return *reinterpret_cast<const bf16x8*>(lds_tile + row * 128 + slot * 16);
 }
 
-template <bool F16, class OT>
-__global__ void __launch_bounds__(256, 2)
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+    if (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+template <bool F16, class OT, int WM, int WAVES_M, int WAVES_N>
+__global__ void __launch_bounds__(WAVES_M * WAVES_N * 64)
 k_gemm_nt_bf16(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, OT* __restrict__ C, int tiles_m,
                int tiles_n, int k_tiles, int64_t lda, int64_t ldb, int64_t ldc) {
-    extern __shared__ __attribute__((aligned(1024))) char lds[];  // 2 stages x (A tile + B tile) = 64 KiB
+    constexpr int WAVES = WAVES_M * WAVES_N;
+    constexpr int TBM = WAVES_M * WM * 32, TBN = WAVES_N * 64;
+    static_assert(TBM == TBN, "square block tiles: both operand tiles share one staging routine");
+    constexpr int TILE_BYTES = TileGeom<TBM>::TILE_BYTES, STAGE_BYTES = TileGeom<TBM>::STAGE_BYTES;
+    constexpr int LOADS_PER_STAGE = 2 * (TBM / 8 / WAVES);  // LDS-DMA instructions per wave per stage
+    extern __shared__ __attribute__((aligned(1024))) char lds[];  // 2 stages x (A tile + B tile)
 
     // XCD-aware tile order: blocks that share an XCD (equal blockIdx % 8, observed round-robin
     // placement; speed only) walk neighbouring tiles so that A/B panels are reused out of that
@@ -173,21 +195,21 @@ k_gemm_nt_bf16(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, OT* _
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WAVES_N, wc = wave % WAVES_N;
 
-    const bf16_t* Ag = A + (int64_t)tm * BM * lda;
-    const bf16_t* Bg = B + (int64_t)tn * BN * ldb;
+    const bf16_t* Ag = A + (int64_t)tm * TBM * lda;
+    const bf16_t* Bg = B + (int64_t)tn * TBN * ldb;
 
-    f32x16 acc[2][2];
+    f32x16 acc[WM][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    stage_tile(Ag, lda, lds, wave, lane);
-    stage_tile(Bg, ldb, lds + TILE_BYTES, wave, lane);
+    stage_tile<TBM, WAVES>(Ag, lda, lds, wave, lane);
+    stage_tile<TBN, WAVES>(Bg, ldb, lds + TILE_BYTES, wave, lane);
 
     const int frow = lane & 31;  // fragment row inside a 32-row MFMA tile
     const int fhalf = lane >> 5; // which 8-wide k half of the 16-wide k-step
@@ -196,9 +218,11 @@ k_gemm_nt_bf16(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, OT* _
         char* cur = lds + (kt & 1) * STAGE_BYTES;
         if (kt + 1 < k_tiles) {
             char* nxt = lds + ((kt + 1) & 1) * STAGE_BYTES;
-            stage_tile(Ag + (int64_t)(kt + 1) * BK, lda, nxt, wave, lane);
-            stage_tile(Bg + (int64_t)(kt + 1) * BK, ldb, nxt + TILE_BYTES, wave, lane);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // tile kt landed; tile kt+1 (8 DMAs) in flight
+            stage_tile<TBM, WAVES>(Ag + (int64_t)(kt + 1) * BK, lda, nxt, wave, lane);
+            stage_tile<TBN, WAVES>(Bg + (int64_t)(kt + 1) * BK, ldb, nxt + TILE_BYTES, wave, lane);
+            // tile kt landed; tile kt+1 (LOADS_PER_STAGE DMAs of this wave) stays in flight across the barrier
+            static_assert(LOADS_PER_STAGE == 8, "the counted vmcnt below assumes 8 LDS-DMA instructions per wave per stage");
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -206,20 +230,15 @@ k_gemm_nt_bf16(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, OT* _
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 a0 = read_frag(cur, wr * 64 + frow, ks * 2 + fhalf);
-            bf16x8 a1 = read_frag(cur, wr * 64 + 32 + frow, ks * 2 + fhalf);
-            bf16x8 b0 = read_frag(cur + TILE_BYTES, wc * 64 + frow, ks * 2 + fhalf);
-            bf16x8 b1 = read_frag(cur + TILE_BYTES, wc * 64 + 32 + frow, ks * 2 + fhalf);
-            if (F16) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, b0), acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, b1), acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1), __builtin_bit_cast(f16x8, b0), acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1), __builtin_bit_cast(f16x8, b1), acc[1][1], 0, 0, 0);
-            } else {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            bf16x8 a[WM];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) a[i] = read_frag(cur, wr * (WM * 32) + i * 32 + frow, ks * 2 + fhalf);
+            const bf16x8 b0 = read_frag(cur + TILE_BYTES, wc * 64 + frow, ks * 2 + fhalf);
+            const bf16x8 b1 = read_frag(cur + TILE_BYTES, wc * 64 + 32 + frow, ks * 2 + fhalf);
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                acc[i][0] = mfma<F16>(a[i], b0, acc[i][0]);
+                acc[i][1] = mfma<F16>(a[i], b1, acc[i][1]);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -228,9 +247,9 @@ k_gemm_nt_bf16(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, OT* _
     }
 
     // C/D layout of v_mfma_f32_32x32x16: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    OT* Cg = C + ((int64_t)tm * BM + wr * 64) * ldc + (int64_t)tn * BN + wc * 64;
+    OT* Cg = C + ((int64_t)tm * TBM + wr * (WM * 32)) * ldc + (int64_t)tn * TBN + wc * 64;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -241,29 +260,41 @@ k_gemm_nt_bf16(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, OT* _
             }
 }
 
-template <bool F16, class OT>
-static void launch_gemm_t(const bf16_t* A, const bf16_t* B, OT* C, int64_t tiles, int64_t M, int64_t N, int64_t K, int64_t lda,
-                          int64_t ldb, int64_t ldc, hipStream_t st) {
+template <bool F16, class OT, int WM, int WAVES_M, int WAVES_N>
+static void launch_gemm_cfg(const bf16_t* A, const bf16_t* B, OT* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+                            int64_t ldb, int64_t ldc, hipStream_t st) {
+    constexpr int TB = WAVES_M * WM * 32;
+    constexpr int SMEM = 2 * TileGeom<TB>::STAGE_BYTES;
+    const int64_t tiles = (M / TB) * (N / TB);
+    KN_REQUIRE(tiles > 0 && tiles < (1ll << 31), KNNCF_E_INVALID, "gemm: grid too large");
     static bool attr_set = false;
     if (!attr_set) {
-        KN_HIP(hipFuncSetAttribute((const void*)k_gemm_nt_bf16<F16, OT>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES));
+        KN_HIP(hipFuncSetAttribute((const void*)k_gemm_nt_bf16<F16, OT, WM, WAVES_M, WAVES_N>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         attr_set = true;
     }
-    k_gemm_nt_bf16<F16, OT><<<(unsigned)tiles, 256, 2 * STAGE_BYTES, st>>>(A, B, C, (int)(M / BM), (int)(N / BN), (int)(K / BK), lda, ldb, ldc);
+    k_gemm_nt_bf16<F16, OT, WM, WAVES_M, WAVES_N><<<(unsigned)tiles, WAVES_M * WAVES_N * 64, SMEM, st>>>(
+        A, B, C, (int)(M / TB), (int)(N / TB), (int)(K / BK), lda, ldb, ldc);
     KN_HIP(hipGetLastError());
 }
 
-// C is fp16 (c_fp16) or fp32; operands fp16 (fp16) or bf16
+template <bool F16, class OT>
+static void launch_gemm_t(const bf16_t* A, const bf16_t* B, OT* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+                          int64_t ldb, int64_t ldc, hipStream_t st) {
+    static const bool force_small = getenv("KNNCF_GEMM_TILE128") != nullptr;  // A/B switch for measurements
+    if (M % 256 == 0 && N % 256 == 0 && !force_small) launch_gemm_cfg<F16, OT, 4, 2, 4>(A, B, C, M, N, K, lda, ldb, ldc, st);
+    else launch_gemm_cfg<F16, OT, 2, 2, 2>(A, B, C, M, N, K, lda, ldb, ldc, st);
+}
+
+// C is fp16 (c_fp16) or fp32; operands fp16 (fp16) or bf16.  M, N multiples of 128 (256 selects the large tile)
 void launch_gemm_nt(const bf16_t* A, const bf16_t* B, void* C, bool c_fp16, int64_t M, int64_t N, int64_t K, int64_t lda,
                     int64_t ldb, int64_t ldc, bool fp16, hipStream_t st) {
-    KN_REQUIRE(M % BM == 0 && N % BN == 0 && K % BK == 0 && K > 0, KNNCF_E_INVALID, "gemm: shape not tile-aligned");
+    KN_REQUIRE(M % 128 == 0 && N % 128 == 0 && K % BK == 0 && K > 0, KNNCF_E_INVALID, "gemm: shape not tile-aligned");
     KN_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, KNNCF_E_INVALID, "gemm: leading dimensions must be multiples of 8");
-    int64_t tiles = (M / BM) * (N / BN);
-    KN_REQUIRE(tiles > 0 && tiles < (1ll << 31), KNNCF_E_INVALID, "gemm: grid too large");
-    if (fp16 && c_fp16) launch_gemm_t<true, _Float16>(A, B, static_cast<_Float16*>(C), tiles, M, N, K, lda, ldb, ldc, st);
-    else if (fp16) launch_gemm_t<true, float>(A, B, static_cast<float*>(C), tiles, M, N, K, lda, ldb, ldc, st);
-    else if (c_fp16) launch_gemm_t<false, _Float16>(A, B, static_cast<_Float16*>(C), tiles, M, N, K, lda, ldb, ldc, st);
-    else launch_gemm_t<false, float>(A, B, static_cast<float*>(C), tiles, M, N, K, lda, ldb, ldc, st);
+    if (fp16 && c_fp16) launch_gemm_t<true, _Float16>(A, B, static_cast<_Float16*>(C), M, N, K, lda, ldb, ldc, st);
+    else if (fp16) launch_gemm_t<true, float>(A, B, static_cast<float*>(C), M, N, K, lda, ldb, ldc, st);
+    else if (c_fp16) launch_gemm_t<false, _Float16>(A, B, static_cast<_Float16*>(C), M, N, K, lda, ldb, ldc, st);
+    else launch_gemm_t<false, float>(A, B, static_cast<float*>(C), M, N, K, lda, ldb, ldc, st);
 }
 
 }  // namespace knncf

@@ -28,9 +28,9 @@ namespace knncf {
 // (barrier-separated phases), so fewer, larger tiles win.
 static constexpr int TPB = 1024;
 static constexpr int NBINS = 4096;
-static constexpr int TCOLS = 24576;  // columns of the row held in LDS at a time (96 KiB)
+static constexpr int TCOLS = 32768;  // columns of the row held in LDS at a time (128 KiB)
 static constexpr int CPT = TCOLS / TPB;  // columns per thread per tile (24 = 3 groups of 8)
-static constexpr int EMAX = 2048;    // row positions whose tail cursors are held in LDS at a time
+static constexpr int EMAX = 1024;    // row positions whose tail cursors (12 B each) are held in LDS at a time
 static constexpr int MAX_PER_THREAD = 16;  // provisional entries per thread in the final compaction
 static constexpr int TAIL_ILP = 4;         // tail entries a wave keeps in flight
 static constexpr int TAIL_CH = 2;          // 64-rater pieces requested ahead per entry
@@ -123,8 +123,8 @@ __global__ void __launch_bounds__(TPB) k_tail_select(const ST* __restrict__ S, i
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int32_t* itile = reinterpret_cast<int32_t*>(smem);            // [TCOLS] tail accumulator, Q7.24
     uint32_t* hist = reinterpret_cast<uint32_t*>(itile + TCOLS);  // [NBINS]
-    int64_t* e_cur = reinterpret_cast<int64_t*>(hist + NBINS);    // [EMAX] cursor into it_user / it_pre
-    int64_t* e_end = e_cur + EMAX;                                // [EMAX]
+    uint32_t* e_cur = hist + NBINS;                               // [EMAX] cursor into it_user / it_pre (n < 2^32)
+    uint32_t* e_end = e_cur + EMAX;                               // [EMAX]
     float* e_x = reinterpret_cast<float*>(e_end + EMAX);          // [EMAX] pre(u, item)
     __shared__ uint32_t wtot[TPB / 64];
     __shared__ float s_thr;
@@ -153,8 +153,8 @@ __global__ void __launch_bounds__(TPB) k_tail_select(const ST* __restrict__ S, i
             const int32_t item = T.s_col[p];
             if (T.colmap[item] < 0) {
                 const int32_t slot = atomicAdd(&s_ne, 1);
-                e_cur[slot] = T.i_ptr[item];
-                e_end[slot] = T.i_ptr[item + 1];
+                e_cur[slot] = (uint32_t)T.i_ptr[item];
+                e_end[slot] = (uint32_t)T.i_ptr[item + 1];
                 e_x[slot] = (float)T.s_pre[p];
             }
         }
@@ -199,8 +199,8 @@ __global__ void __launch_bounds__(TPB) k_tail_select(const ST* __restrict__ S, i
                                 else hi = mid;
                             }
                             const int32_t slot = atomicAdd(&s_ne, 1);
-                            e_cur[slot] = lo;
-                            e_end[slot] = end;
+                            e_cur[slot] = (uint32_t)lo;
+                            e_end[slot] = (uint32_t)end;
                             e_x[slot] = (float)T.s_pre[p];
                         }
                     }
@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(TPB) k_tail_select(const ST* __restrict__ S, i
                 // one wave per tail entry; TAIL_ILP entries x TAIL_CH 64-rater pieces are requested before any
                 // is consumed (the loop is latency-bound: rater lists are short and come from L2/HBM)
                 for (int32_t e0 = wave; e0 < ne; e0 += TAIL_ILP * (TPB / 64)) {
-                    int64_t q[TAIL_ILP], qe[TAIL_ILP];
+                    uint32_t q[TAIL_ILP], qe[TAIL_ILP];
                     float x[TAIL_ILP];
                     bool live[TAIL_ILP];
 #pragma unroll
@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(TPB) k_tail_select(const ST* __restrict__ S, i
                         for (int j = 0; j < TAIL_ILP; ++j)
 #pragma unroll
                             for (int k = 0; k < TAIL_CH; ++k) {
-                                const int64_t qq = q[j] + 64 * k + lane;
+                                const uint32_t qq = q[j] + 64 * k + lane;
                                 v[j][k] = 0x7fffffff;
                                 y[j][k] = 0.f;
                                 if (live[j] && qq < qe[j]) {
@@ -265,68 +265,94 @@ __global__ void __launch_bounds__(TPB) k_tail_select(const ST* __restrict__ S, i
                 }
                 __syncthreads();
             }
-            // final values of this thread's columns (registers)
+            // read the accumulator out (vectorised) and clear it for the next tile: only this thread touches
+            // these cells between the barriers
 #pragma unroll
             for (int j = 0; j < CPT / 8; ++j) {
                 const int32_t c0 = 8 * (threadIdx.x + TPB * j);
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    if (c0 + i < t1 - t0) {
-                        sx[8 * j + i] += (float)itile[c0 + i] * TAIL_UNFIX;
-                        itile[c0 + i] = 0;  // clean for the next tile (only this thread touches these cells here)
-                    }
+                int4* cell = reinterpret_cast<int4*>(itile + c0);
+                const int4 a = cell[0], b = cell[1];
+                cell[0] = make_int4(0, 0, 0, 0);
+                cell[1] = make_int4(0, 0, 0, 0);
+                sx[8 * j + 0] += (float)a.x * TAIL_UNFIX; sx[8 * j + 1] += (float)a.y * TAIL_UNFIX;
+                sx[8 * j + 2] += (float)a.z * TAIL_UNFIX; sx[8 * j + 3] += (float)a.w * TAIL_UNFIX;
+                sx[8 * j + 4] += (float)b.x * TAIL_UNFIX; sx[8 * j + 5] += (float)b.y * TAIL_UNFIX;
+                sx[8 * j + 6] += (float)b.z * TAIL_UNFIX; sx[8 * j + 7] += (float)b.w * TAIL_UNFIX;
             }
         }
-        // cumulative histogram.  Only values >= the current threshold can matter for the k-th largest
-        // (the threshold never exceeds it), which also keeps the LDS atomics off the crowded bins near 0.
-        // First tile: a 1/8 subsample bootstraps a valid threshold (the k-th largest of a subset is a
-        // lower bound of the k-th largest of the row).
-        float floor_thr = (t0 == 0) ? -INFINITY : s_thr;
-        for (int pass = (t0 == 0 ? 0 : 1); pass < 2; ++pass) {
-            const bool mine = (t0 != 0) || (((threadIdx.x & 7) == 0) == (pass == 0));
-            if (mine) {
+        if (tile_no == 0) {
+            // First tile: a 1/8 subsample bootstraps a valid threshold (the k-th largest of a subset is a lower
+            // bound of the k-th largest of the row); then only values above it enter the cumulative histogram,
+            // which keeps the LDS atomics off the crowded bins near 0.
+            float floor_thr = -INFINITY;
+            for (int pass = 0; pass < 2; ++pass) {
+                if (((threadIdx.x & 7) == 0) == (pass == 0)) {
 #pragma unroll
-                for (int j = 0; j < CPT / 8; ++j) {
-                    const int32_t v0 = t0 + 8 * (threadIdx.x + TPB * j);
+                    for (int j = 0; j < CPT / 8; ++j) {
+                        const int32_t v0 = t0 + 8 * (threadIdx.x + TPB * j);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int32_t v = v0 + i;
-                        const float x = sx[8 * j + i];
-                        if (v < t1 && v != u && x >= floor_thr) atomicAdd(&hist[sim_bin(x)], 1u);
+                        for (int i = 0; i < 8; ++i) {
+                            const int32_t v = v0 + i;
+                            const float x = sx[8 * j + i];
+                            if (v < t1 && v != u && x >= floor_thr) atomicAdd(&hist[sim_bin(x)], 1u);
+                        }
                     }
                 }
-            }
-            if (t0 == 0 && pass == 0) {
                 __syncthreads();
                 block_threshold(hist, wtot, &s_thr, kk, eps);
                 floor_thr = s_thr;
             }
-        }
-        // The threshold is refreshed after the first tiles only (it can only rise; a stale one just lets a few
-        // more provisional entries through) — every refresh costs three workgroup barriers.
-        if (tile_no <= 1 || tile_no == 3) {
-            __syncthreads();
-            block_threshold(hist, wtot, &s_thr, kk, eps);
-        }
-        const float thr = s_thr;  // valid for every column seen so far
+            const float thr = s_thr;
 #pragma unroll
-        for (int j = 0; j < CPT / 8; ++j) {
-            const int32_t v0 = t0 + 8 * (threadIdx.x + TPB * j);
+            for (int j = 0; j < CPT / 8; ++j) {
+                const int32_t v0 = t0 + 8 * (threadIdx.x + TPB * j);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int32_t v = v0 + i;
-                const float x = sx[8 * j + i];
-                if (v < t1 && v != u && x >= thr) {
-                    const uint32_t pos = atomicAdd(&s_count, 1u);
-                    if (pos < (uint32_t)cap) {
-                        out_idx[pos] = v;
-                        out_apx[pos] = x;
+                for (int i = 0; i < 8; ++i) {
+                    const int32_t v = v0 + i;
+                    const float x = sx[8 * j + i];
+                    if (v < t1 && v != u && x >= thr) {
+                        const uint32_t pos = atomicAdd(&s_count, 1u);
+                        if (pos < (uint32_t)cap) {
+                            out_idx[pos] = v;
+                            out_apx[pos] = x;
+                        }
                     }
                 }
+            }
+        } else {
+            // Later tiles: one fused pass with the threshold known so far (it can only rise; a stale one just lets a
+            // few more provisional entries through).  The kernel is VALU-bound here (2.6e10 panel entries per
+            // step), so a group of 8 is first rejected by its maximum; survivors are rare.
+            const float thr = s_thr;
+#pragma unroll
+            for (int j = 0; j < CPT / 8; ++j) {
+                const float* x8 = &sx[8 * j];
+                const float m = fmaxf(fmaxf(fmaxf(x8[0], x8[1]), fmaxf(x8[2], x8[3])), fmaxf(fmaxf(x8[4], x8[5]), fmaxf(x8[6], x8[7])));
+                if (m >= thr) {
+                    const int32_t v0 = t0 + 8 * (threadIdx.x + TPB * j);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int32_t v = v0 + i;
+                        const float x = x8[i];
+                        if (x >= thr && v < t1 && v != u) {
+                            atomicAdd(&hist[sim_bin(x)], 1u);
+                            const uint32_t pos = atomicAdd(&s_count, 1u);
+                            if (pos < (uint32_t)cap) {
+                                out_idx[pos] = v;
+                                out_apx[pos] = x;
+                            }
+                        }
+                    }
+                }
+            }
+            if (tile_no == 1) {  // one refresh after 2 tiles (~30 % of the row): costs three barriers, tightens the rest
+                __syncthreads();
+                block_threshold(hist, wtot, &s_thr, kk, eps);
             }
         }
         __syncthreads();
     }
+
 
     // ---- compaction of the provisional list by the final threshold (in place) ------------------------
     const uint32_t prov = s_count;
@@ -367,7 +393,7 @@ template <class ST>
 static void launch_tail_select_t(const TailArgs& T, const ST* S, int64_t lds, int32_t n_rows, const int32_t* d_row_user,
                                  int32_t U, int32_t kk, float eps, int32_t cap, int32_t* cand_idx, float* cand_approx,
                                  int32_t* cand_cnt, hipStream_t st) {
-    const size_t smem = (size_t)TCOLS * 4 + (size_t)NBINS * 4 + (size_t)EMAX * (8 + 8 + 4);
+    const size_t smem = (size_t)TCOLS * 4 + (size_t)NBINS * 4 + (size_t)EMAX * (4 + 4 + 4);
     static bool attr_set = false;
     if (!attr_set) {
         KN_HIP(hipFuncSetAttribute((const void*)k_tail_select<ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
