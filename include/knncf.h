@@ -71,7 +71,7 @@ typedef struct knncf_config {
     int64_t workspace_bytes; /* cap for the similarity panel + dense operand panels; 0 = auto */
     uint32_t flags;          /* KNNCF_FLAG_* */
     uint32_t head_items;     /* hybrid similarity: the head_items most-rated items go through the dense MFMA
-                                GEMM, the sparse tail is added by fp32 atomics.  0 = cost model,
+                                GEMM, the sparse tail is accumulated per panel row in LDS (fixed point).  0 = cost model,
                                 KNNCF_HEAD_ALL = every item dense */
 } knncf_config;
 #define KNNCF_HEAD_ALL 0xffffffffu
@@ -79,9 +79,9 @@ typedef struct knncf_config {
 /* per-stage device timings of the last fit / neighbour build / predict, milliseconds */
 typedef struct knncf_timings {
     double prep_ms;     /* K0-K4: id compaction, CSR/CSC, means, deviations, norms */
-    double densify_ms;  /* CSR -> bf16 panels */
+    double densify_ms;  /* CSR -> 16-bit operand panels */
     double gemm_ms;     /* K5 similarity GEMM (all launches) */
-    double tail_ms;     /* K5 sparse tail of the hybrid similarity (fp32 atomics into the panel) */
+    double tail_ms;     /* K5 sparse tail when run as its own pass (0: fused into select_ms) */
     double select_ms;   /* K6 threshold + shortlist */
     double rerank_ms;   /* K6b exact fp64 re-rank + top-k sort */
     double predict_ms;  /* K7-K9 prediction + MAE */

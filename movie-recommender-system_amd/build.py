@@ -42,7 +42,7 @@ def build(force=False, verbose=False):
 
     def compile_one(job):
         src, obj = job
-        cmd = [_hipcc()] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [_hipcc()] + FLAGS + os.environ.get("KNNCF_EXTRA_HIPCC_FLAGS", "").split() + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -51,7 +51,6 @@ struct knncf_handle {
     hipStream_t stream2 = nullptr;
     DArr<bf16_t> Apanel[2];
     DArr<float> S[2];
-    DArr<int32_t> row_of_user[2];
     hipEvent_t ev_produced[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr}, ev_ready = nullptr;
     int32_t* pinned_cnt = nullptr;
     size_t pinned_cap = 0;
@@ -213,7 +212,7 @@ int32_t shortlist_cap(int32_t k, int32_t U) {
 
 // Width H of the dense head of the hybrid similarity.  Cost model (measured rates, MI355X): a dense
 // column costs 2 * rows * U flops on the MFMA GEMM; a tail item with c raters costs c^2 * rows / U
-// scattered fp32 atomics.  Items are in descending popularity, so the optimum is a prefix.
+// LDS accumulator updates in k_tail_select.  Items are in descending popularity, so the optimum is a prefix.
 int32_t choose_head(knncf_handle* h, int32_t rows_total) {
     Train& tr = h->tr;
     const int32_t I = tr.I;
@@ -293,7 +292,6 @@ void build_neighbors(knncf_handle* h, int32_t count) {
     for (int s = 0; s < slots; ++s) {
         h->S[s].ensure((size_t)(R * U_pad * s_elem + 3) / 4);  // DArr<float> used as raw storage
         h->Apanel[s].ensure((size_t)R * K_pad);
-        h->row_of_user[s].ensure(tr.U);
     }
     const int32_t cap = shortlist_cap(nt.k, tr.U);
     const bool verify = (h->cfg.flags & KNNCF_FLAG_VERIFY_BOUND) != 0;

@@ -11,6 +11,9 @@ namespace knncf {
 
 typedef __bf16 bf16_t;
 
+// columns of a similarity row that select.hip holds in LDS at a time (prep.hip tabulates the tile crossings)
+static constexpr int SELECT_TCOLS = 32768;
+
 // ---- sort_util.hip (rocPRIM device radix sort / unique; K0 plumbing only) ---------------
 struct SortWorkspace {
     DArr<char> tmp;
@@ -59,6 +62,10 @@ struct Train {
     int64_t ib_words = 0;        // 64-bit words per item row = ceil(U / 64); 0 = not built (too large)
     DArr<uint64_t> item_bits;    // [I * ib_words]
     DArr<uint32_t> item_rank;    // [I * ib_words]
+    // where each item's rater list crosses the column tiles of select.hip: it_tile[i][t] = first entry q of item i
+    // with it_user[q] >= t * SELECT_TCOLS (t = 0 .. tile_stride-1; the last one is the list's end)
+    int32_t tile_stride = 0;
+    DArr<uint32_t> it_tile;      // [I * tile_stride]
     DArr<int32_t> pop_item;  // [I] dense items by descending number of raters
     std::vector<int64_t> pop_count;  // host: rater counts in that order
     double global_avg = 0.0;
@@ -93,15 +100,9 @@ void launch_dense_ids(const Train& tr, const int32_t* d_users, const int32_t* d_
 void launch_densify(const Train& tr, const int32_t* d_rows, int32_t row_begin, int32_t n_rows,
                     const int32_t* d_colmap, bf16_t* panel, int64_t ld, int64_t panel_rows, bool fp16,
                     hipStream_t st);
-// sparse tail: S[row_of_user[a]][b] += pre(a,i) * pre(b,i) for every tail item i = pop_item[first_tail + j]
-// and every pair of its raters (a in the panel, b any): fp32 atomics
-void launch_tail_scatter(const Train& tr, int32_t first_tail, const int32_t* d_row_of_user, float* S, int64_t lds,
-                         hipStream_t st);
 // colmap[item] = column of the dense head panel (popularity rank < H) or -1 (tail)
 void launch_colmap(const Train& tr, int32_t H, int32_t* d_colmap, hipStream_t st);
-// row_of_user[u] = panel row of user u or -1
-void launch_row_of_user(int32_t U, int32_t n_rows, const int32_t* d_rows, int32_t* d_row_of_user, hipStream_t st);
-// C[M][ldc] (fp32) = A[M][K] * B[N][K]^T, bf16 in / fp32 accumulate; M, N multiples of 128, K of 64
+// C[M][ldc] (fp32 or fp16) = A[M][K] * B[N][K]^T, 16-bit in / fp32 accumulate; M, N multiples of 128, K of 64
 void launch_gemm_nt(const bf16_t* A, const bf16_t* B, void* C, bool c_fp16, int64_t M, int64_t N, int64_t K,
                     int64_t lda, int64_t ldb, int64_t ldc, bool fp16, hipStream_t st);
 

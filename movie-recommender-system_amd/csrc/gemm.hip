@@ -1,13 +1,14 @@
 // gemm.hip — K5: the user x user adjusted-cosine similarity as a blocked MFMA GEMM on gfx950.
 //
-//   S[M x N] (fp32) = A[M x K] * B[N x K]^T,  A/B = rows of the preprocessed-rating matrix
-//   rounded to bf16 (both operands K-contiguous: the "NT" form, ideal for LDS staging).
+//   S[M x N] (fp16 or fp32) = A[M x K] * B[N x K]^T,  A/B = rows of the preprocessed-rating matrix
+//   (head columns only) rounded to fp16 (default) or bf16; both operands K-contiguous: the "NT"
+//   form, ideal for LDS staging.
 //
-// The bf16 result only has to be a FILTER: select.hip keeps every candidate within a rigorous
+// The 16-bit result only has to be a FILTER: select.hip keeps every candidate within a rigorous
 // error band of the k-th value and the fp64 re-rank decides.
 //
-// Kernel structure (v1): 128x128 block tile, BK = 64, 256 threads = 4 waves as 2x2, each wave a
-// 64x64 sub-tile = 2x2 v_mfma_f32_32x32x16_bf16 accumulators (64 acc VGPRs).  Operand tiles go
+// Kernel structure: BK = 64, each wave owns a (WM*32) x 64 sub-tile of v_mfma_f32_32x32x16_{f16,bf16}
+// accumulators; 128x128 tile / 4 waves or 256x256 tile / 8 waves.  Operand tiles go
 // HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction) into a 2-deep
 // ring; the LDS image is lane-linear as the DMA requires, with the bank swizzle applied on the
 // SOURCE address (16-B chunk c of row r sits in slot c ^ ((r >> 1) & 7), conflict-free for
@@ -54,7 +55,7 @@ void launch_densify(const Train& tr, const int32_t* d_rows, int32_t row_begin, i
     KN_HIP(hipGetLastError());
 }
 
-// ---- hybrid similarity: column map of the dense head, sparse tail by fp32 atomics -----------
+// ---- hybrid similarity: column map of the dense head (the sparse tail is added in select.hip) --
 __global__ void k_colmap(int32_t I, int32_t H, const int32_t* __restrict__ pop_item, int32_t* __restrict__ colmap) {
     int32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= I) return;
@@ -63,67 +64,6 @@ __global__ void k_colmap(int32_t I, int32_t H, const int32_t* __restrict__ pop_i
 
 void launch_colmap(const Train& tr, int32_t H, int32_t* d_colmap, hipStream_t st) {
     k_colmap<<<(unsigned)ceil_div(tr.I, 256), 256, 0, st>>>(tr.I, H, tr.pop_item.p, d_colmap);
-    KN_HIP(hipGetLastError());
-}
-
-// The user x item matrix is ~0.25 % dense but its columns are extremely skewed: a few thousand
-// popular items hold ~99 % of sum_i |U(i)|^2.  Those go through the dense MFMA GEMM; every other
-// item i contributes pre(a,i) * pre(b,i) to S[a][b] for each pair of its raters, added here with
-// no-return fp32 atomics (memory-side, order-free: S is only a filter, select.hip's error band
-// covers the fp32 roundings).  One workgroup per tail item; raters that own a panel row are
-// compacted into LDS, then the (panel rater) x (rater) pairs are spread over the threads.
-static constexpr int TAIL_TPB = 256;
-static constexpr int TAIL_LDS = 2048;
-
-__global__ void __launch_bounds__(TAIL_TPB) k_tail_scatter(const int64_t* __restrict__ i_ptr, const int32_t* __restrict__ pop_item,
-                                                           int32_t first_tail, const int32_t* __restrict__ it_user,
-                                                           const float* __restrict__ it_pre, const int32_t* __restrict__ row_of_user,
-                                                           float* __restrict__ S, int64_t ld) {
-    __shared__ int32_t a_row[TAIL_LDS];
-    __shared__ float a_val[TAIL_LDS];
-    __shared__ int32_t a_count;
-    const int32_t item = pop_item[first_tail + blockIdx.x];
-    const int64_t b0 = i_ptr[item], cnt = i_ptr[item + 1] - b0;
-    for (int64_t c0 = 0; c0 < cnt; c0 += TAIL_LDS) {  // panel raters, TAIL_LDS at a time
-        if (threadIdx.x == 0) a_count = 0;
-        __syncthreads();
-        const int64_t c1 = min(cnt, c0 + TAIL_LDS);
-        for (int64_t q = c0 + threadIdx.x; q < c1; q += TAIL_TPB) {
-            int32_t r = row_of_user[it_user[b0 + q]];
-            if (r >= 0) {
-                int32_t slot = atomicAdd(&a_count, 1);
-                a_row[slot] = r;
-                a_val[slot] = it_pre[b0 + q];
-            }
-        }
-        __syncthreads();
-        const int64_t na = a_count;
-        const int64_t pairs = na * cnt;
-        for (int64_t e = threadIdx.x; e < pairs; e += TAIL_TPB) {
-            const int64_t a = e / cnt, b = e - a * cnt;
-            atomicAdd(&S[(int64_t)a_row[a] * ld + it_user[b0 + b]], a_val[a] * it_pre[b0 + b]);
-        }
-        __syncthreads();
-    }
-}
-
-void launch_tail_scatter(const Train& tr, int32_t first_tail, const int32_t* d_row_of_user, float* S, int64_t lds,
-                         hipStream_t st) {
-    const int32_t n_tail = tr.I - first_tail;
-    if (n_tail <= 0) return;
-    k_tail_scatter<<<n_tail, TAIL_TPB, 0, st>>>(tr.i_ptr.p, tr.pop_item.p, first_tail, tr.it_user.p, tr.it_pre.p,
-                                                d_row_of_user, S, lds);
-    KN_HIP(hipGetLastError());
-}
-
-__global__ void k_row_of_user(int32_t n_rows, const int32_t* __restrict__ rows, int32_t* __restrict__ row_of_user) {
-    int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < n_rows) row_of_user[rows[r]] = r;
-}
-
-void launch_row_of_user(int32_t U, int32_t n_rows, const int32_t* d_rows, int32_t* d_row_of_user, hipStream_t st) {
-    KN_HIP(hipMemsetAsync(d_row_of_user, 0xff, (size_t)U * sizeof(int32_t), st));
-    k_row_of_user<<<(unsigned)ceil_div(n_rows, 256), 256, 0, st>>>(n_rows, d_rows, d_row_of_user);
     KN_HIP(hipGetLastError());
 }
 

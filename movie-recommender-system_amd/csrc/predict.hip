@@ -16,10 +16,6 @@
 namespace knncf {
 
 static constexpr int TPB = 256;
-// neighbours probed per lane at once.  Measured: 5 is 15 % SLOWER than 1 — the probes are bound by L2 sector
-// bandwidth (each binary-search step touches its own 64-B sector), not by latency.
-static constexpr int PROBE_ILP = 1;
-
 struct PredArgs {
     const int64_t* u_ptr;
     const int32_t* s_col;
@@ -46,16 +42,6 @@ struct PredArgs {
     const unsigned long long* item_bits;
     const uint32_t* item_rank;
 };
-
-__device__ __forceinline__ int64_t find_item(const PredArgs& A, int32_t user, int32_t col) {
-    int64_t lo = A.u_ptr[user], hi = A.u_ptr[user + 1], e = hi;
-    while (lo < hi) {
-        int64_t mid = (lo + hi) >> 1;
-        if (A.s_col[mid] < col) lo = mid + 1;
-        else hi = mid;
-    }
-    return (lo < e && A.s_col[lo] == col) ? lo : -1;
-}
 
 // predictor :568-585 given the user's mean and the weighted-sum deviation
 __device__ __forceinline__ double combine(double ua, double wsd) { return ua + wsd * scale_fn(ua + wsd, ua); }

@@ -463,6 +463,22 @@ __global__ void k_item_rank(int32_t I, int64_t words, const unsigned long long* 
     }
 }
 
+// it_tile[i][t] = lower bound of t * SELECT_TCOLS in item i's ascending rater list (absolute entry index)
+__global__ void k_item_tiles(int32_t I, int32_t stride, const int64_t* __restrict__ i_ptr, const int32_t* __restrict__ it_user,
+                             uint32_t* __restrict__ it_tile) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (int64_t)I * stride) return;
+    const int32_t i = (int32_t)(g / stride), t = (int32_t)(g - (int64_t)i * stride);
+    int64_t lo = i_ptr[i], hi = i_ptr[i + 1];
+    const int64_t bound = (int64_t)t * SELECT_TCOLS;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (it_user[mid] < bound) lo = mid + 1;
+        else hi = mid;
+    }
+    it_tile[g] = (uint32_t)lo;
+}
+
 __global__ void k_col_keys(int64_t n, const int32_t* __restrict__ s_col, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
@@ -491,6 +507,9 @@ void prep_commit(Train& tr, PrepScratch& sc, hipStream_t st) {
     sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.v32_a.p, sc.v32_b.p, n, bits_for(I), st);
     k_item_major<<<nblocks(n), TPB, 0, st>>>(n, sc.v32_b.p, tr.s_user.p, tr.s_pre.p, tr.s_dev.p, tr.s_t.p, tr.it_user.p,
                                              tr.it_pre.p, tr.it_dev.p, tr.it_t.p);
+    tr.tile_stride = (int32_t)ceil_div(tr.U, SELECT_TCOLS) + 1;
+    tr.it_tile.ensure((size_t)I * tr.tile_stride);
+    k_item_tiles<<<nblocks((int64_t)I * tr.tile_stride), TPB, 0, st>>>(I, tr.tile_stride, tr.i_ptr.p, tr.it_user.p, tr.it_tile.p);
     // per-item rater bitmaps + rank prefixes for the prediction probes (skipped when they would not fit)
     {
         const int64_t words = ceil_div(tr.U, 64);

@@ -2,11 +2,13 @@
 //
 // The dense MFMA GEMM (gemm.hip) leaves S[u][v] = sum over the H most-rated items (fp16 or fp32
 // storage).  For row u this kernel (one 1024-thread workgroup per row) walks the row ONCE, a column tile
-// (24 576 columns = 96 KiB of LDS) at a time:
+// (32 768 columns = 128 KiB of LDS) at a time; the panel entries of tile t+1 are requested before tile t is
+// processed:
 //   1. SPARSE TAIL: for every tail item i rated by u and every rater v of i inside the tile,
-//      pre(u,i) * pre(v,i) is accumulated in Q7.24 fixed point with integer LDS atomics (the rater lists
-//      are sorted by user, so each list is swept once across the tiles with a per-entry cursor kept in
-//      LDS; rows with more than EMAX ratings re-derive their cursors per tile by binary search);
+//      pre(u,i) * pre(v,i) is accumulated in Q7.24 fixed point with integer LDS atomics.  The rater lists
+//      are sorted by user and prep.hip tabulates where each list crosses a tile boundary (it_tile), so the
+//      tile's work is a set of [begin, end) ranges; they are cut into 64-rater pieces and the pieces are
+//      dealt evenly to the 16 waves (a prefix sum over the entries), several pieces in flight per wave;
 //   2. the tile's final values S + tail stay in registers and enter a cumulative 4096-bin LDS histogram;
 //      the bin holding the k-th largest value SEEN SO FAR gives a threshold that can only rise as more
 //      columns are seen, so every v of the tile with value >= (bin lower edge - 2 eps) is appended to a
@@ -17,28 +19,43 @@
 // the exact top-k; rerank.hip decides.  HBM-bound: S is read exactly once and never written back; the
 // tail's per-pair products never touch HBM atomics.
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "engine.h"
 
 namespace knncf {
+
+#ifdef KNNCF_SELECT_PROFILE
+__device__ unsigned long long g_phase[16];
+#define PH(i) do { if (threadIdx.x == 0) { const long long now_ = clock64(); atomicAdd(&g_phase[i], (unsigned long long)(now_ - ph_t)); ph_t = now_; } } while (0)
+#else
+#define PH(i) do {} while (0)
+#endif
 
 // One 1024-thread workgroup per CU with the largest tile that fits.  Measured alternative: two 512-thread
 // workgroups per CU with 48 KiB tiles (twice as many tiles per row) ran 1.7x SLOWER — the cost is per tile
 // (barrier-separated phases), so fewer, larger tiles win.
 static constexpr int TPB = 1024;
 static constexpr int NBINS = 4096;
-static constexpr int TCOLS = 32768;  // columns of the row held in LDS at a time (128 KiB)
-static constexpr int CPT = TCOLS / TPB;  // columns per thread per tile (24 = 3 groups of 8)
-static constexpr int EMAX = 1024;    // row positions whose tail cursors (12 B each) are held in LDS at a time
+static constexpr int TCOLS = SELECT_TCOLS;  // columns of the row held in LDS at a time (128 KiB)
+static constexpr int CPT = TCOLS / TPB;  // columns per thread per tile (32 = 4 groups of 8)
+static constexpr int NG = CPT / 8;
+static constexpr int EMAX = 512;     // row positions whose tail entries (16 B each) are held in LDS at a time
+static constexpr int PMAX = 2048;    // pieces per (chunk, tile) with a direct piece -> entry table in LDS
+static constexpr int MAXT = 8;       // tiles whose per-entry rater counts are packed into registers
 static constexpr int MAX_PER_THREAD = 16;  // provisional entries per thread in the final compaction
-static constexpr int TAIL_ILP = 4;         // tail entries a wave keeps in flight
-static constexpr int TAIL_CH = 2;          // 64-rater pieces requested ahead per entry
+static constexpr int TAIL_ILP = 16;        // 64-rater pieces a wave keeps in flight
 // the tail is accumulated in Q7.24 fixed point with integer LDS atomics (ds_add_u32; the float form
 // ds_add_f32 measured ~1.4x slower here): |sum| <= 1, each product is quantised with error <= 2^-25,
 // which the per-common-item term of row_eps covers
 static constexpr float TAIL_FIX = 16777216.0f;
 static constexpr float TAIL_UNFIX = 1.0f / 16777216.0f;
+
+// LDS cell of tile column c: the low and the high 4 columns of every group of 8 live in separate halves of the
+// array, so that the read-out (one thread = 8 consecutive columns) is two conflict-free 16-byte accesses
+__device__ __forceinline__ int32_t acc_index(int32_t c) { return (((c >> 3) << 2) | (c & 3)) + ((c & 4) ? TCOLS / 2 : 0); }
 
 __device__ __forceinline__ int sim_bin(float x) {
     int b = (int)floorf((x + 1.0f) * (NBINS / 2));
@@ -59,6 +76,8 @@ struct TailArgs {
     const int64_t* i_ptr;   // item-major rows, raters ascending
     const int32_t* it_user;
     const float* it_pre;
+    const uint32_t* it_tile;  // [I][tile_stride]: first entry of the item's list with user >= t * TCOLS
+    int32_t tile_stride;
     int32_t has_tail;
 };
 
@@ -103,17 +122,36 @@ __device__ __forceinline__ void block_threshold(const uint32_t* hist, uint32_t* 
     __syncthreads();
 }
 
-// 8 consecutive panel entries starting at a multiple of 8 (rows are padded to ld, a multiple of 128)
-__device__ __forceinline__ void load8(const float* p, float* out) {
-    const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
-    out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w; out[4] = b.x; out[5] = b.y; out[6] = b.z; out[7] = b.w;
-}
-__device__ __forceinline__ void load8(const _Float16* p, float* out) {
+// 8 consecutive panel entries starting at a multiple of 8 (rows are padded to ld, a multiple of 256): the
+// load and the conversion are separate so that the next tile's entries can be in flight while this one is used
+template <class ST>
+struct Raw8;
+template <>
+struct Raw8<float> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const float* p) {
+        a = reinterpret_cast<const float4*>(p)[0];
+        b = reinterpret_cast<const float4*>(p)[1];
+    }
+    __device__ __forceinline__ void zero() { a = make_float4(0.f, 0.f, 0.f, 0.f); b = a; }
+    __device__ __forceinline__ void unpack(float* out) const {
+        out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w; out[4] = b.x; out[5] = b.y; out[6] = b.z; out[7] = b.w;
+    }
+};
+template <>
+struct Raw8<_Float16> {
     typedef __attribute__((ext_vector_type(8))) _Float16 h8;
-    const h8 v = *reinterpret_cast<const h8*>(p);
+    h8 v;
+    __device__ __forceinline__ void load(const _Float16* p) { v = *reinterpret_cast<const h8*>(p); }
+    __device__ __forceinline__ void zero() {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) out[i] = (float)v[i];
-}
+        for (int i = 0; i < 8; ++i) v[i] = (_Float16)0.f;
+    }
+    __device__ __forceinline__ void unpack(float* out) const {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) out[i] = (float)v[i];
+    }
+};
 
 template <class ST>
 __global__ void __launch_bounds__(TPB) k_tail_select(const ST* __restrict__ S, int64_t ld, int32_t n_rows,
@@ -121,17 +159,23 @@ __global__ void __launch_bounds__(TPB) k_tail_select(const ST* __restrict__ S, i
                                                      int32_t kk, float eps_base, int32_t cap, int32_t* __restrict__ cand_idx,
                                                      float* __restrict__ cand_approx, int32_t* __restrict__ cand_cnt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int32_t* itile = reinterpret_cast<int32_t*>(smem);            // [TCOLS] tail accumulator, Q7.24
+    int32_t* itile = reinterpret_cast<int32_t*>(smem);            // [TCOLS] tail accumulator, Q7.24, swizzled (acc_index)
     uint32_t* hist = reinterpret_cast<uint32_t*>(itile + TCOLS);  // [NBINS]
-    uint32_t* e_cur = hist + NBINS;                               // [EMAX] cursor into it_user / it_pre (n < 2^32)
-    uint32_t* e_end = e_cur + EMAX;                               // [EMAX]
-    float* e_x = reinterpret_cast<float*>(e_end + EMAX);          // [EMAX] pre(u, item)
+    float* e_x = reinterpret_cast<float*>(hist + NBINS);          // [EMAX] pre(u, item) * 2^24
+    uint32_t* e_b = reinterpret_cast<uint32_t*>(e_x + EMAX);      // [EMAX] this tile's range of the item's rater list
+    uint32_t* e_e = e_b + EMAX;                                   // [EMAX]
+    uint32_t* e_ps = e_e + EMAX;                                  // [EMAX] exclusive prefix of the 64-rater piece counts
+    int32_t* e_item = reinterpret_cast<int32_t*>(e_ps);           //   (aliased: the item of the entry, until its owner read it)
+    uint16_t* piece_e = reinterpret_cast<uint16_t*>(e_ps + EMAX); // [PMAX] entry of every piece
     __shared__ uint32_t wtot[TPB / 64];
     __shared__ float s_thr;
     __shared__ uint32_t s_count;
     __shared__ int32_t s_ne;
     const int32_t r = blockIdx.x;
     if (r >= n_rows) return;
+#ifdef KNNCF_SELECT_PROFILE
+    long long ph_t = clock64();
+#endif
     const int32_t u = row_user[r];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t ub = T.u_ptr[u], ue = T.u_ptr[u + 1];
@@ -139,220 +183,270 @@ __global__ void __launch_bounds__(TPB) k_tail_select(const ST* __restrict__ S, i
     const ST* row = S + (int64_t)r * ld;
     int32_t* out_idx = cand_idx + (int64_t)r * cap;
     float* out_apx = cand_approx + (int64_t)r * cap;
+    // this thread's 32 columns of a tile: group j covers columns t0 + 8 (tid + 1024 j) .. + 7
+    Raw8<ST> raw[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        const int64_t v0 = 8 * (threadIdx.x + TPB * j);
+        if (v0 < ld) raw[j].load(row + v0);
+        else raw[j].zero();
+    }
     for (int b = threadIdx.x; b < NBINS; b += TPB) hist[b] = 0;
-    if (threadIdx.x == 0) { s_count = 0; s_ne = 0; }
+    if (threadIdx.x == 0) { s_count = 0; s_ne = 0; s_thr = -INFINITY; }
     __syncthreads();
 
-    // tail entries of the row.  Rows of up to EMAX ratings (all but the heaviest raters) collect them once and
-    // keep one cursor per entry in LDS across the tiles; longer rows take EMAX positions at a time and
-    // re-derive the cursors of every chunk for every tile by binary search.
-    const bool single = (ue - ub) <= EMAX;
+    // tail entries of the row, EMAX row positions (a "chunk") at a time.  Rows of up to EMAX ratings (all but the
+    // heaviest raters) collect them once; longer rows re-collect every chunk for every tile.
     const int n_chunks = T.has_tail ? (int)((ue - ub + EMAX - 1) / EMAX) : 0;
-    if (single && n_chunks > 0) {
-        for (int64_t p = ub + threadIdx.x; p < ue; p += TPB) {
+    const int n_tiles = T.tile_stride - 1;
+    const bool reg_counts = n_chunks == 1 && n_tiles <= MAXT;
+    auto collect = [&](int ch) {
+        const int64_t cb = ub + (int64_t)ch * EMAX, ce = min(ue, cb + EMAX);
+        for (int64_t p = cb + threadIdx.x; p < ce; p += TPB) {
             const int32_t item = T.s_col[p];
             if (T.colmap[item] < 0) {
                 const int32_t slot = atomicAdd(&s_ne, 1);
-                e_cur[slot] = (uint32_t)T.i_ptr[item];
-                e_end[slot] = (uint32_t)T.i_ptr[item + 1];
-                e_x[slot] = (float)T.s_pre[p];
+                e_item[slot] = item;
+                e_x[slot] = (float)T.s_pre[p] * TAIL_FIX;
             }
         }
+    };
+    if (n_chunks == 1) {
+        collect(0);
         __syncthreads();
     }
-    const bool any_tail = n_chunks > 0 && (!single || s_ne > 0);
+    const bool any_tail = n_chunks > 1 || (n_chunks == 1 && s_ne > 0);
+    // single-chunk rows: thread e owns entry e for the whole row.  Its item's rater counts per tile (<= 32768 each)
+    // are packed into registers, so the tile loop needs no global read for the ranges
+    const uint32_t* my_tb = T.it_tile;
+    uint32_t cur_b = 0, cw[MAXT / 2];
+#pragma unroll
+    for (int t = 0; t < MAXT / 2; ++t) cw[t] = 0;
+    if (n_chunks == 1 && (int32_t)threadIdx.x < s_ne) {
+        my_tb = T.it_tile + (int64_t)e_item[threadIdx.x] * T.tile_stride;
+        if (reg_counts) {
+            uint32_t tbv[MAXT + 1];
+#pragma unroll
+            for (int t = 0; t <= MAXT; ++t) tbv[t] = my_tb[min(t, n_tiles)];
+            cur_b = tbv[0];
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) cw[t >> 1] |= (tbv[t + 1] - tbv[t]) << (16 * (t & 1));
+        }
+    }
     if (any_tail) {  // the accumulator starts clean; afterwards every tile's read-out clears what it reads
         for (int32_t c = threadIdx.x; c < TCOLS; c += TPB) itile[c] = 0;
-        __syncthreads();
     }
+    __syncthreads();  // also: every owner has read e_item before e_ps (its alias) is written
 
+    PH(0);  // preamble: collect, clears
     int tile_no = 0;
     for (int32_t t0 = 0; t0 < U; t0 += TCOLS, ++tile_no) {
-        const int32_t t1 = min(U, t0 + TCOLS);
-        // this thread's 24 columns of the tile: group j covers columns t0 + 8 (tid + 1024 j) .. + 7.  The loads
-        // are issued first so that their HBM latency hides behind the tail accumulation
-        float sx[CPT];
-#pragma unroll
-        for (int j = 0; j < CPT / 8; ++j) {
-            const int64_t v0 = (int64_t)t0 + 8 * (threadIdx.x + TPB * j);
-            if (v0 < ld) load8(row + v0, &sx[8 * j]);
-            else {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) sx[8 * j + i] = 0.f;
-            }
-        }
         if (any_tail) {
             for (int ch = 0; ch < n_chunks; ++ch) {
-                if (!single) {  // collect this chunk's entries with cursors at the tile's first column
+                if (n_chunks > 1) {
                     __syncthreads();
                     if (threadIdx.x == 0) s_ne = 0;
                     __syncthreads();
-                    const int64_t cb = ub + (int64_t)ch * EMAX, ce = min(ue, cb + EMAX);
-                    for (int64_t p = cb + threadIdx.x; p < ce; p += TPB) {
-                        const int32_t item = T.s_col[p];
-                        if (T.colmap[item] < 0) {
-                            int64_t lo = T.i_ptr[item], hi = T.i_ptr[item + 1];
-                            const int64_t end = hi;
-                            while (lo < hi) {
-                                const int64_t mid = (lo + hi) >> 1;
-                                if (T.it_user[mid] < t0) lo = mid + 1;
-                                else hi = mid;
-                            }
-                            const int32_t slot = atomicAdd(&s_ne, 1);
-                            e_cur[slot] = (uint32_t)lo;
-                            e_end[slot] = (uint32_t)end;
-                            e_x[slot] = (float)T.s_pre[p];
-                        }
-                    }
+                    collect(ch);
                     __syncthreads();
                 }
                 const int32_t ne = s_ne;
-                // one wave per tail entry; TAIL_ILP entries x TAIL_CH 64-rater pieces are requested before any
-                // is consumed (the loop is latency-bound: rater lists are short and come from L2/HBM)
-                for (int32_t e0 = wave; e0 < ne; e0 += TAIL_ILP * (TPB / 64)) {
-                    uint32_t q[TAIL_ILP], qe[TAIL_ILP];
-                    float x[TAIL_ILP];
-                    bool live[TAIL_ILP];
-#pragma unroll
-                    for (int j = 0; j < TAIL_ILP; ++j) {
-                        const int32_t e = e0 + j * (TPB / 64);
-                        live[j] = e < ne;
-                        q[j] = live[j] ? e_cur[e] : 0;
-                        qe[j] = live[j] ? e_end[e] : 0;
-                        x[j] = live[j] ? e_x[e] : 0.f;
-                        live[j] = live[j] && q[j] < qe[j];
+                // the entries' ranges inside this tile and the exclusive prefix of their piece counts
+                uint32_t np = 0;
+                if ((int32_t)threadIdx.x < ne) {
+                    uint32_t qb, cnt;
+                    if (reg_counts) {
+                        const uint32_t w01 = (tile_no & 2) ? cw[1] : cw[0], w23 = (tile_no & 2) ? cw[3] : cw[2];
+                        const uint32_t w = (tile_no & 4) ? w23 : w01;
+                        cnt = (w >> (16 * (tile_no & 1))) & 0xffffu;
+                        qb = cur_b;
+                        cur_b += cnt;
+                    } else {
+                        const uint32_t* tb = (n_chunks > 1 ? T.it_tile + (int64_t)e_item[threadIdx.x] * T.tile_stride : my_tb) + tile_no;
+                        qb = tb[0];
+                        cnt = tb[1] - qb;
                     }
-                    bool any_live = true;
-                    while (any_live) {
-                        int32_t v[TAIL_ILP][TAIL_CH];
-                        float y[TAIL_ILP][TAIL_CH];
+                    e_b[threadIdx.x] = qb;
+                    e_e[threadIdx.x] = qb + cnt;
+                    np = (cnt + 63u) >> 6;
+                }
+                uint32_t incl = np;
 #pragma unroll
-                        for (int j = 0; j < TAIL_ILP; ++j)
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t up = __shfl_up(incl, o);
+                    if (lane >= o) incl += up;
+                }
+                if (lane == 63 && wave < EMAX / 64) wtot[wave] = incl;
+                __syncthreads();
+                uint32_t off = 0, P = 0;
 #pragma unroll
-                            for (int k = 0; k < TAIL_CH; ++k) {
-                                const uint32_t qq = q[j] + 64 * k + lane;
-                                v[j][k] = 0x7fffffff;
-                                y[j][k] = 0.f;
-                                if (live[j] && qq < qe[j]) {
-                                    v[j][k] = T.it_user[qq];
-                                    y[j][k] = T.it_pre[qq];
-                                }
+                for (int w = 0; w < EMAX / 64; ++w) {
+                    const uint32_t sw = wtot[w];
+                    P += sw;
+                    if (w < wave) off += sw;
+                }
+                if ((int32_t)threadIdx.x < ne) {
+                    const uint32_t excl = off + incl - np;
+                    e_ps[threadIdx.x] = excl;
+                    if (P <= PMAX)
+                        for (uint32_t k2 = 0; k2 < np; ++k2) piece_e[excl + k2] = (uint16_t)threadIdx.x;
+                }
+                __syncthreads();
+                PH(2);  // ranges + prefix scan
+                // pieces [p_lo, p_hi) of this wave, 64 at a time: lane l looks up the entry of piece pw + l and keeps its
+                // range; then the pieces' loads are issued TAIL_ILP deep
+                const uint32_t p_lo = (uint32_t)(((uint64_t)P * wave) / (TPB / 64));
+                const uint32_t p_hi = (uint32_t)(((uint64_t)P * (wave + 1)) / (TPB / 64));
+                for (uint32_t pw = p_lo; pw < p_hi; pw += 64) {
+                    const uint32_t n_here = min(64u, p_hi - pw);
+                    uint32_t d_q = 0, d_end = 0;
+                    float d_x = 0.f;
+                    if ((uint32_t)lane < n_here) {
+                        const uint32_t p = pw + lane;
+                        int32_t e;
+                        if (P <= PMAX) {
+                            e = piece_e[p];
+                        } else {  // largest e with e_ps[e] <= p (a non-empty entry, as p < P)
+                            int32_t lo = 0, hi = ne - 1;
+                            while (lo < hi) {
+                                const int32_t mid = (lo + hi + 1) >> 1;
+                                if (e_ps[mid] <= p) lo = mid;
+                                else hi = mid - 1;
                             }
-                        any_live = false;
-#pragma unroll
-                        for (int j = 0; j < TAIL_ILP; ++j) {
-                            if (!live[j]) continue;  // wave-uniform
-#pragma unroll
-                            for (int k = 0; k < TAIL_CH; ++k) {
-                                if (!live[j]) break;
-                                const bool in = v[j][k] < t1;
-                                if (in) atomicAdd(&itile[v[j][k] - t0], __float2int_rn(x[j] * y[j][k] * TAIL_FIX));
-                                const int n_in = __popcll(__ballot(in));
-                                q[j] += n_in;
-                                // fewer than 64 inside: reached the tile's end (raters ascend) or the list's end
-                                live[j] = (n_in == 64) && q[j] < qe[j];
-                            }
-                            any_live = any_live || live[j];
+                            e = lo;
                         }
+                        d_q = e_b[e] + ((p - e_ps[e]) << 6);
+                        d_end = e_e[e];
+                        d_x = e_x[e];
                     }
-                    if (single) {
+                    PH(3);  // piece descriptors
+                    for (uint32_t j0 = 0; j0 < n_here; j0 += TAIL_ILP) {
+                        int32_t v[TAIL_ILP];
+                        float y[TAIL_ILP];
 #pragma unroll
                         for (int j = 0; j < TAIL_ILP; ++j) {
-                            const int32_t e = e0 + j * (TPB / 64);
-                            if (e < ne && lane == 0) e_cur[e] = q[j];
+                            const int src = (int)min(j0 + j, 63u);
+                            const uint32_t q = (uint32_t)__shfl((int)d_q, src) + lane;
+                            const uint32_t qend = (j0 + j < n_here) ? (uint32_t)__shfl((int)d_end, src) : 0u;
+                            v[j] = -1;
+                            y[j] = 0.f;
+                            if (q < qend) {
+                                v[j] = T.it_user[q];
+                                y[j] = T.it_pre[q];
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < TAIL_ILP; ++j) {
+                            const float xf = __shfl(d_x, (int)min(j0 + j, 63u));
+                            if (v[j] >= 0) atomicAdd(&itile[acc_index(v[j] - t0)], __float2int_rn(xf * y[j]));
                         }
                     }
                 }
+                PH(4);  // piece loads + LDS atomics (this wave)
                 __syncthreads();
+                PH(5);  // wait for the other waves
             }
-            // read the accumulator out (vectorised) and clear it for the next tile: only this thread touches
-            // these cells between the barriers
+        }
+        // the tile's panel entries (requested one tile ago) are needed only now; the next tile's are requested here,
+        // so that they arrive behind the select work of this tile and the tail work of the next
+        float sx[CPT];
 #pragma unroll
-            for (int j = 0; j < CPT / 8; ++j) {
-                const int32_t c0 = 8 * (threadIdx.x + TPB * j);
-                int4* cell = reinterpret_cast<int4*>(itile + c0);
-                const int4 a = cell[0], b = cell[1];
-                cell[0] = make_int4(0, 0, 0, 0);
-                cell[1] = make_int4(0, 0, 0, 0);
+        for (int j = 0; j < NG; ++j) raw[j].unpack(&sx[8 * j]);
+        if (t0 + TCOLS < U) {  // request the next tile's panel entries now: they arrive behind this tile's work
+#pragma unroll
+            for (int j = 0; j < NG; ++j) {
+                const int64_t v0 = (int64_t)t0 + TCOLS + 8 * (threadIdx.x + TPB * j);
+                if (v0 < ld) raw[j].load(row + v0);
+                else raw[j].zero();
+            }
+        }
+        if (t0 + TCOLS > U || (u >= t0 && u < t0 + TCOLS)) {  // the user itself and the padding never qualify
+#pragma unroll
+            for (int j = 0; j < NG; ++j) {
+                const int32_t v0 = t0 + 8 * (threadIdx.x + TPB * j);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (v0 + i >= U || v0 + i == u) sx[8 * j + i] = -INFINITY;
+            }
+        }
+        PH(1);  // unpack + next tile's requests
+        if (any_tail) {
+            // read the accumulator out and clear it for the next tile (only this thread touches these cells between
+            // the barriers).  acc_index keeps both 16-byte halves of a group at a 16-byte lane stride: no bank conflicts
+#pragma unroll
+            for (int j = 0; j < NG; ++j) {
+                const int32_t g = threadIdx.x + TPB * j;
+                int4* lo4 = reinterpret_cast<int4*>(itile + 4 * g);
+                int4* hi4 = reinterpret_cast<int4*>(itile + TCOLS / 2 + 4 * g);
+                const int4 a = *lo4, b = *hi4;
+                *lo4 = make_int4(0, 0, 0, 0);
+                *hi4 = make_int4(0, 0, 0, 0);
                 sx[8 * j + 0] += (float)a.x * TAIL_UNFIX; sx[8 * j + 1] += (float)a.y * TAIL_UNFIX;
                 sx[8 * j + 2] += (float)a.z * TAIL_UNFIX; sx[8 * j + 3] += (float)a.w * TAIL_UNFIX;
                 sx[8 * j + 4] += (float)b.x * TAIL_UNFIX; sx[8 * j + 5] += (float)b.y * TAIL_UNFIX;
                 sx[8 * j + 6] += (float)b.z * TAIL_UNFIX; sx[8 * j + 7] += (float)b.w * TAIL_UNFIX;
             }
         }
+        PH(6);  // read-out
+        float gm[NG];  // group maxima: a group of 8 is first rejected as a whole (the kernel is VALU/latency-bound)
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const float* x8 = &sx[8 * j];
+            gm[j] = fmaxf(fmaxf(fmaxf(x8[0], x8[1]), fmaxf(x8[2], x8[3])), fmaxf(fmaxf(x8[4], x8[5]), fmaxf(x8[6], x8[7])));
+        }
         if (tile_no == 0) {
-            // First tile: a 1/8 subsample bootstraps a valid threshold (the k-th largest of a subset is a lower
-            // bound of the k-th largest of the row); then only values above it enter the cumulative histogram,
-            // which keeps the LDS atomics off the crowded bins near 0.
-            float floor_thr = -INFINITY;
-            for (int pass = 0; pass < 2; ++pass) {
-                if (((threadIdx.x & 7) == 0) == (pass == 0)) {
+            // First tile: bootstrap a threshold from per-thread (or per-group, or per-column) maxima — the kk-th largest
+            // of any set of maxima over disjoint column sets is a lower bound of the kk-th largest value of the row,
+            // and a tight one (the top values sit in different threads) — with one histogram atomic per maximum
+            // instead of one per column.
+            if (kk <= TPB / 3) {
+                const float m = fmaxf(fmaxf(gm[0], gm[1]), fmaxf(gm[2], gm[3]));
+                if (m > -INFINITY) atomicAdd(&hist[sim_bin(m)], 1u);
+            } else if (kk <= (TPB * NG) / 3) {
 #pragma unroll
-                    for (int j = 0; j < CPT / 8; ++j) {
-                        const int32_t v0 = t0 + 8 * (threadIdx.x + TPB * j);
+                for (int j = 0; j < NG; ++j)
+                    if (gm[j] > -INFINITY) atomicAdd(&hist[sim_bin(gm[j])], 1u);
+            } else {
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const int32_t v = v0 + i;
-                            const float x = sx[8 * j + i];
-                            if (v < t1 && v != u && x >= floor_thr) atomicAdd(&hist[sim_bin(x)], 1u);
-                        }
-                    }
-                }
-                __syncthreads();
-                block_threshold(hist, wtot, &s_thr, kk, eps);
-                floor_thr = s_thr;
+                for (int i = 0; i < CPT; ++i)
+                    if (sx[i] > -INFINITY) atomicAdd(&hist[sim_bin(sx[i])], 1u);
             }
+            __syncthreads();
+            block_threshold(hist, wtot, &s_thr, kk, eps);
+            for (int b = threadIdx.x; b < NBINS; b += TPB) hist[b] = 0;  // the real histogram starts below
+            __syncthreads();
+        }
+        {
+            // One fused pass with the threshold known so far (it can only rise; a stale one just lets a few more
+            // provisional entries through): survivors enter the cumulative histogram and the provisional shortlist.
             const float thr = s_thr;
 #pragma unroll
-            for (int j = 0; j < CPT / 8; ++j) {
-                const int32_t v0 = t0 + 8 * (threadIdx.x + TPB * j);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int32_t v = v0 + i;
-                    const float x = sx[8 * j + i];
-                    if (v < t1 && v != u && x >= thr) {
-                        const uint32_t pos = atomicAdd(&s_count, 1u);
-                        if (pos < (uint32_t)cap) {
-                            out_idx[pos] = v;
-                            out_apx[pos] = x;
-                        }
-                    }
-                }
-            }
-        } else {
-            // Later tiles: one fused pass with the threshold known so far (it can only rise; a stale one just lets a
-            // few more provisional entries through).  The kernel is VALU-bound here (2.6e10 panel entries per
-            // step), so a group of 8 is first rejected by its maximum; survivors are rare.
-            const float thr = s_thr;
-#pragma unroll
-            for (int j = 0; j < CPT / 8; ++j) {
-                const float* x8 = &sx[8 * j];
-                const float m = fmaxf(fmaxf(fmaxf(x8[0], x8[1]), fmaxf(x8[2], x8[3])), fmaxf(fmaxf(x8[4], x8[5]), fmaxf(x8[6], x8[7])));
-                if (m >= thr) {
+            for (int j = 0; j < NG; ++j) {
+                if (gm[j] >= thr) {
                     const int32_t v0 = t0 + 8 * (threadIdx.x + TPB * j);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        const int32_t v = v0 + i;
-                        const float x = x8[i];
-                        if (x >= thr && v < t1 && v != u) {
+                        const float x = sx[8 * j + i];
+                        if (x >= thr && x > -INFINITY) {
                             atomicAdd(&hist[sim_bin(x)], 1u);
                             const uint32_t pos = atomicAdd(&s_count, 1u);
                             if (pos < (uint32_t)cap) {
-                                out_idx[pos] = v;
+                                out_idx[pos] = v0 + i;
                                 out_apx[pos] = x;
                             }
                         }
                     }
                 }
             }
-            if (tile_no == 1) {  // one refresh after 2 tiles (~30 % of the row): costs three barriers, tightens the rest
+            if (tile_no == 1) {  // one refresh after 2 tiles: costs three barriers, tightens the rest
                 __syncthreads();
                 block_threshold(hist, wtot, &s_thr, kk, eps);
             }
         }
+        PH(tile_no == 0 ? 7 : 8);  // histogram + emit
         __syncthreads();
+        PH(9);
     }
-
 
     // ---- compaction of the provisional list by the final threshold (in place) ------------------------
     const uint32_t prov = s_count;
@@ -387,13 +481,27 @@ __global__ void __launch_bounds__(TPB) k_tail_select(const ST* __restrict__ S, i
     }
     __syncthreads();
     if (threadIdx.x == 0) cand_cnt[r] = (int32_t)s_count;
+    PH(10);  // final compaction
 }
+
+#ifdef KNNCF_SELECT_PROFILE
+void select_profile_dump() {
+    unsigned long long h[16];
+    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof(h));
+    unsigned long long tot = 0;
+    for (int i = 0; i < 16; ++i) tot += h[i];
+    fprintf(stderr, "[select profile] cycles per phase (thread 0 of every block), total %.3e\n", (double)tot);
+    for (int i = 0; i <= 10; ++i) fprintf(stderr, "  phase %2d: %6.2f %%\n", i, 100.0 * (double)h[i] / (double)tot);
+    memset(h, 0, sizeof(h));
+    hipMemcpyToSymbol(HIP_SYMBOL(g_phase), h, sizeof(h));
+}
+#endif
 
 template <class ST>
 static void launch_tail_select_t(const TailArgs& T, const ST* S, int64_t lds, int32_t n_rows, const int32_t* d_row_user,
                                  int32_t U, int32_t kk, float eps, int32_t cap, int32_t* cand_idx, float* cand_approx,
                                  int32_t* cand_cnt, hipStream_t st) {
-    const size_t smem = (size_t)TCOLS * 4 + (size_t)NBINS * 4 + (size_t)EMAX * (4 + 4 + 4);
+    const size_t smem = (size_t)TCOLS * 4 + (size_t)NBINS * 4 + (size_t)EMAX * 16 + (size_t)PMAX * 2;
     static bool attr_set = false;
     if (!attr_set) {
         KN_HIP(hipFuncSetAttribute((const void*)k_tail_select<ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -401,6 +509,10 @@ static void launch_tail_select_t(const TailArgs& T, const ST* S, int64_t lds, in
     }
     k_tail_select<ST><<<n_rows, TPB, smem, st>>>(S, lds, n_rows, d_row_user, T, U, kk, eps, cap, cand_idx, cand_approx, cand_cnt);
     KN_HIP(hipGetLastError());
+#ifdef KNNCF_SELECT_PROFILE
+    KN_HIP(hipStreamSynchronize(st));
+    select_profile_dump();
+#endif
 }
 
 void launch_tail_select(const Train& tr, const int32_t* d_colmap, bool has_tail, const void* S, bool s_fp16, int64_t lds,
@@ -411,7 +523,10 @@ void launch_tail_select(const Train& tr, const int32_t* d_colmap, bool has_tail,
     const int32_t U = tr.U;
     int32_t kk = k < U - 1 ? k : U - 1;
     if (kk < 1) kk = 1;
-    TailArgs T{tr.u_ptr.p, tr.s_col.p, tr.s_pre.p, d_colmap, tr.i_ptr.p, tr.it_user.p, tr.it_pre.p, has_tail ? 1 : 0};
+    KN_REQUIRE(!has_tail || tr.tile_stride == (int32_t)ceil_div(U, TCOLS) + 1, KNNCF_E_STATE, "select: tile table missing");
+    static const bool debug_no_tail = getenv("KNNCF_DEBUG_NO_TAIL") != nullptr;  // timing experiments only: wrong results
+    if (debug_no_tail) has_tail = false;
+    TailArgs T{tr.u_ptr.p, tr.s_col.p, tr.s_pre.p, d_colmap, tr.i_ptr.p, tr.it_user.p, tr.it_pre.p, tr.it_tile.p, tr.tile_stride, has_tail ? 1 : 0};
     if (s_fp16) launch_tail_select_t(T, static_cast<const _Float16*>(S), lds, n_rows, d_row_user, U, kk, eps, cap, cand_idx, cand_approx, cand_cnt, st);
     else launch_tail_select_t(T, static_cast<const float*>(S), lds, n_rows, d_row_user, U, kk, eps, cap, cand_idx, cand_approx, cand_cnt, st);
 }
