@@ -176,8 +176,8 @@ def main():
                                    tm["gemm_flops_algorithmic"], MFMA_BF16_DENSE_PEAK_TFLOPS, "TFLOP/s",
                                    "2 * rows * (U-1) * head_items flops per launch"),
             "k_tail_select": roof("k_tail_select (sparse tail + histogram select)", "hbm", tm["select_ms"],
-                                  tm["select_row_bytes"] + 8.0 * tm["tail_pair_updates"], HBM_PEAK_TBPS, "TB/s",
-                                  "4 B * rows * U panel entries read once + 8 B per tail pair product (rater id + value)"),
+                                  tm["select_row_bytes"] + 4.0 * tm["tail_pair_updates"], HBM_PEAK_TBPS, "TB/s",
+                                  "panel entry size (2 B fp16 / 4 B fp32) * rows * U, read once + 4 B per tail pair product (packed column | Q0.16 value)"),
             "k_rerank": roof("k_rerank (exact fp64 re-rank + top-k)", "hbm", tm["rerank_ms"], tm["rerank_row_bytes"],
                              HBM_PEAK_TBPS, "TB/s", "12 B * ratings of every shortlisted candidate"),
             "k_predict_knn": roof("k_predict_knn (weighted-sum prediction + MAE)", "hbm", tm["predict_ms"] * launches / steps,

@@ -94,7 +94,7 @@ typedef struct knncf_timings {
     int64_t head_items;            /* dense head width used by the last build */
     double tail_pair_updates;      /* sum over tail items of (raters in panel) x (raters) */
     double rerank_row_bytes;       /* K6b algorithmic traffic: 12 B x ratings of every re-ranked candidate */
-    double select_row_bytes;       /* K6 algorithmic traffic: 4 B x (rows x users) similarity panel entries read */
+    double select_row_bytes;       /* K6 algorithmic traffic: panel entry size x (rows x users) similarity panel entries read */
 } knncf_timings;
 
 const char* knncf_version(void);

@@ -298,6 +298,7 @@ void build_neighbors(knncf_handle* h, int32_t count) {
     h->sel.cand_idx.ensure((size_t)R * cap);
     h->sel.cand_approx.ensure((size_t)R * cap);
     h->sel.cand_cnt.ensure(R);
+    h->sel.cand_eps.ensure(R);
     h->sel.stats.ensure(4);
     KN_HIP(hipMemsetAsync(h->sel.stats.p, 0, 4 * sizeof(double), st));  // [0] bound check, [1] candidate row entries
     if (h->pinned_cap < (size_t)count) {
@@ -339,14 +340,14 @@ void build_neighbors(knncf_handle* h, int32_t count) {
             // sparse tail (LDS atomics per row tile) + histogram select, fused: one pass over S
             Stage s(h, &h->tm.select_ms, sc);
             launch_tail_select(tr, h->colmap.p, head < tr.I, h->S[slot].p, s_fp16, U_pad, rows, d_rows, nt.k, eps, cap,
-                               h->sel.cand_idx.p, h->sel.cand_approx.p, h->sel.cand_cnt.p, sc);
+                               h->sel.cand_idx.p, h->sel.cand_approx.p, h->sel.cand_cnt.p, h->sel.cand_eps.p, sc);
             h->tm.tail_pair_updates += h->tail_pairs_full * ((double)rows / (double)tr.U);
-            h->tm.select_row_bytes += 4.0 * (double)rows * (double)tr.U;
+            h->tm.select_row_bytes += (double)s_elem * (double)rows * (double)tr.U;
         }
         if (overlap) KN_HIP(hipEventRecord(h->ev_consumed[slot], sc));
         {
             Stage s(h, &h->tm.rerank_ms, sc);
-            launch_rerank(tr, nt, rows, d_rows, cap, h->sel.cand_idx.p, h->sel.cand_approx.p, h->sel.cand_cnt.p, eps,
+            launch_rerank(tr, nt, rows, d_rows, cap, h->sel.cand_idx.p, h->sel.cand_approx.p, h->sel.cand_cnt.p, h->sel.cand_eps.p,
                           h->sel.stats.p, verify, sc);
         }
         if (!overlap) KN_HIP(hipEventRecord(h->ev_consumed[slot], sc));

@@ -12,7 +12,7 @@ namespace knncf {
 typedef __bf16 bf16_t;
 
 // columns of a similarity row that select.hip holds in LDS at a time (prep.hip tabulates the tile crossings)
-static constexpr int SELECT_TCOLS = 32768;
+static constexpr int SELECT_TCOLS = 32768;  // 2^15: it_pack keeps the column inside its tile in 15 bits
 
 // ---- sort_util.hip (rocPRIM device radix sort / unique; K0 plumbing only) ---------------
 struct SortWorkspace {
@@ -54,7 +54,7 @@ struct Train {
     DArr<double> item_avg, item_dev_hash, item_dev_file;  // [I]
     // item-major copies for the sparse tail of the hybrid similarity (fp32 is enough: it only filters)
     DArr<int32_t> it_user;   // [n] dense user of the q-th entry in (item, user ascending) order
-    DArr<float> it_pre;      // [n] preprocessed rating of that entry (fp32: the tail only filters)
+    DArr<uint32_t> it_pack;  // [n] LDS cell of (user mod SELECT_TCOLS) << 17 | Q0.16 preprocessed rating: the sparse tail's 4-byte entry
     DArr<double> it_dev;     // [n] normalized deviation of that entry (prediction gathers)
     DArr<uint32_t> it_t;     // [n] training file row of that entry (order of ratedI(i) :508-517)
     // per-item rater bitmaps over the dense user index + per-word exclusive rank prefixes: "did user x rate
@@ -122,6 +122,7 @@ struct SelectScratch {
     DArr<int32_t> cand_idx;   // [rows * cap]
     DArr<float> cand_approx;  // [rows * cap] (KNNCF_FLAG_VERIFY_BOUND)
     DArr<int32_t> cand_cnt;   // [rows] (> cap == overflow)
+    DArr<float> cand_eps;     // [rows] the error band of the row's approximate similarities
     DArr<double> stats;       // [4]: max bound violation, ...
     DArr<double> row_exact;   // fallback: [U] exact similarities of one row
     DArr<uint64_t> fb_keys_a, fb_keys_b;
@@ -132,11 +133,11 @@ struct SelectScratch {
 // candidates v with S[r][v] >= T_r - 2 eps
 void launch_tail_select(const Train& tr, const int32_t* d_colmap, bool has_tail, const void* S, bool s_fp16, int64_t lds,
                         int32_t n_rows, const int32_t* d_row_user, int32_t k, float eps, int32_t cap,
-                        int32_t* cand_idx, float* cand_approx, int32_t* cand_cnt, hipStream_t st);
+                        int32_t* cand_idx, float* cand_approx, int32_t* cand_cnt, float* cand_eps, hipStream_t st);
 // exact fp64 similarities of the shortlists in reference order, stable top-k
 void launch_rerank(const Train& tr, NeighborTable& nt, int32_t n_rows, const int32_t* d_row_user,
                    int32_t cap, const int32_t* cand_idx, const float* cand_approx,
-                   const int32_t* cand_cnt, float eps, double* d_stats, bool verify, hipStream_t st);
+                   const int32_t* cand_cnt, const float* cand_eps, double* d_stats, bool verify, hipStream_t st);
 // exact similarities of one user against everyone (fallback + scalar queries)
 void launch_exact_row(const Train& tr, const NeighborTable& nt, int32_t user, int64_t user_seq,
                       double* d_out, hipStream_t st);

@@ -421,13 +421,22 @@ void prep_fit(Train& tr, PrepScratch& sc, int32_t shard_rank, int32_t shard_coun
 // (user, deviation, file row) for the prediction's "which neighbours rated item i" probes
 __global__ void k_item_major(int64_t n, const uint32_t* __restrict__ perm_iu, const int32_t* __restrict__ s_user,
                              const double* __restrict__ s_pre, const double* __restrict__ s_dev,
-                             const uint32_t* __restrict__ s_t, int32_t* __restrict__ it_user, float* __restrict__ it_pre,
+                             const uint32_t* __restrict__ s_t, int32_t* __restrict__ it_user, uint32_t* __restrict__ it_pack,
                              double* __restrict__ it_dev, uint32_t* __restrict__ it_t) {
     int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n) return;
     uint32_t p = perm_iu[q];
     it_user[q] = s_user[p];
-    it_pre[q] = (float)s_pre[p];
+    {  // tail word of select.hip: LDS cell of the column inside its tile (15 bits, high) | preprocessed rating as
+       // signed Q0.16 (17 bits, low).  The cell index already carries select.hip's accumulator layout (the low and the
+       // high 4 columns of every group of 8 live in separate halves: conflict-free 16-byte read-out), so the kernel
+       // spends no instruction on it.
+        int32_t qv = __double2int_rn(s_pre[p] * 65536.0);
+        qv = min(max(qv, -65536), 65535);
+        const uint32_t c = (uint32_t)s_user[p] & (uint32_t)(SELECT_TCOLS - 1);
+        const uint32_t cell = (((c >> 3) << 2) | (c & 3u)) + ((c & 4u) ? (uint32_t)(SELECT_TCOLS / 2) : 0u);
+        it_pack[q] = (cell << 17) | ((uint32_t)qv & 0x1ffffu);
+    }
     it_dev[q] = s_dev[p];
     it_t[q] = s_t[p];
 }
@@ -499,14 +508,14 @@ void prep_commit(Train& tr, PrepScratch& sc, hipStream_t st) {
     const int32_t I = tr.I;
     // item-major copies + popularity order (hybrid similarity: dense head / sparse tail)
     // (item, user ascending) order: a stable sort of the user-major positions by item
-    tr.it_user.alloc(n); tr.it_pre.alloc(n); tr.it_dev.alloc(n); tr.it_t.alloc(n); tr.pop_item.alloc(I);
+    tr.it_user.alloc(n); tr.it_pack.alloc(n); tr.it_dev.alloc(n); tr.it_t.alloc(n); tr.pop_item.alloc(I);
     sc.k64_a.ensure(std::max<int64_t>(n, I)); sc.k64_b.ensure(std::max<int64_t>(n, I));
     sc.v32_a.ensure(std::max<int64_t>(n, I)); sc.v32_b.ensure(n);
     k_col_keys<<<nblocks(n), TPB, 0, st>>>(n, tr.s_col.p, sc.k64_a.p, sc.v32_a.p);
     KN_HIP(hipGetLastError());
     sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.v32_a.p, sc.v32_b.p, n, bits_for(I), st);
     k_item_major<<<nblocks(n), TPB, 0, st>>>(n, sc.v32_b.p, tr.s_user.p, tr.s_pre.p, tr.s_dev.p, tr.s_t.p, tr.it_user.p,
-                                             tr.it_pre.p, tr.it_dev.p, tr.it_t.p);
+                                             tr.it_pack.p, tr.it_dev.p, tr.it_t.p);
     tr.tile_stride = (int32_t)ceil_div(tr.U, SELECT_TCOLS) + 1;
     tr.it_tile.ensure((size_t)I * tr.tile_stride);
     k_item_tiles<<<nblocks((int64_t)I * tr.tile_stride), TPB, 0, st>>>(I, tr.tile_stride, tr.i_ptr.p, tr.it_user.p, tr.it_tile.p);

@@ -118,9 +118,6 @@ __device__ __forceinline__ bool ranks_before(double sa, int32_t ia, double sb, i
     return sa > sb || (sa == sb && ia < ib);
 }
 
-__device__ __forceinline__ float row_eps(float eps_base, int64_t row_len) {  // see select.hip
-    return eps_base + (float)row_len * 2.0f * 6.1e-8f;
-}
 
 // ---- K6b kernel ----------------------------------------------------------------------------------
 // One workgroup per panel row u.  u's item set lives in LDS as a BITMAP over the dense item index
@@ -239,8 +236,8 @@ __global__ void __launch_bounds__(TPB) k_rerank(Rows R, const int64_t* __restric
                                                 const int32_t* __restrict__ cand_idx, const float* __restrict__ cand_approx,
                                                 const int32_t* __restrict__ cand_cnt, int32_t kk, int32_t kcap,
                                                 int32_t* __restrict__ nbr_idx, double* __restrict__ nbr_sim,
-                                                int32_t* __restrict__ nbr_cnt, float eps_base, double* __restrict__ stats,
-                                                int32_t words) {
+                                                int32_t* __restrict__ nbr_cnt, const float* __restrict__ cand_eps,
+                                                double* __restrict__ stats, int32_t words) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t part[TPB];
     double* ssim = reinterpret_cast<double*>(smem);            // [TILE]
@@ -286,7 +283,7 @@ __global__ void __launch_bounds__(TPB) k_rerank(Rows R, const int64_t* __restric
     }
     const int32_t ufirst = R.s_col[ub], ulast = R.s_col[ub + nu - 1];
     const int64_t seq_u = seq[u];
-    const float eps = row_eps(eps_base, nu);
+    const float eps = cand_eps[r];  // the band select.hip used for this row (KNNCF_FLAG_VERIFY_BOUND)
     const int32_t* my_cand = cand_idx + (int64_t)r * cap;
     lds_f64 wb = (lds_f64)(wbuf + wave * WBUF);
     double worst = -1.0;
@@ -363,7 +360,7 @@ __global__ void __launch_bounds__(TPB) k_rerank(Rows R, const int64_t* __restric
 template <int TILE>
 static void launch_rerank_tile(const Rows& R, const Train& tr, NeighborTable& nt, int32_t n_rows, const int32_t* d_row_user,
                                int32_t cap, const int32_t* cand_idx, const float* cand_approx, const int32_t* cand_cnt,
-                               float eps, double* d_stats, hipStream_t st) {
+                               const float* cand_eps, double* d_stats, hipStream_t st) {
     const int32_t words = (int32_t)ceil_div(tr.I, 32);
     const size_t smem = (size_t)TILE * 8 + (size_t)UPRE_LDS * 8 + (size_t)(TPB / 64) * WBUF * 8 + (size_t)TILE * 4 +
                         (size_t)words * 8;
@@ -374,19 +371,19 @@ static void launch_rerank_tile(const Rows& R, const Train& tr, NeighborTable& nt
         attr = smem;
     }
     k_rerank<TILE><<<n_rows, TPB, smem, st>>>(R, nt.seq.p, n_rows, d_row_user, cap, cand_idx, cand_approx, cand_cnt, nt.kcap,
-                                              nt.kcap, nt.idx.p, nt.sim.p, nt.cnt.p, eps, d_stats, words);
+                                              nt.kcap, nt.idx.p, nt.sim.p, nt.cnt.p, cand_eps, d_stats, words);
     KN_HIP(hipGetLastError());
 }
 
 void launch_rerank(const Train& tr, NeighborTable& nt, int32_t n_rows, const int32_t* d_row_user, int32_t cap,
-                   const int32_t* cand_idx, const float* cand_approx, const int32_t* cand_cnt, float eps,
+                   const int32_t* cand_idx, const float* cand_approx, const int32_t* cand_cnt, const float* cand_eps,
                    double* d_stats, bool verify, hipStream_t st) {
     if (n_rows <= 0) return;
     KN_REQUIRE(nt.kcap <= 1024, KNNCF_E_UNSUPPORTED, "k > 1024 is not supported by the re-rank kernel yet");
     Rows R{tr.u_ptr.p, tr.s_col.p, tr.s_t.p, tr.s_pre.p};
     const float* apx = verify ? cand_approx : nullptr;
-    if (nt.kcap <= 512) launch_rerank_tile<1024>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, eps, d_stats, st);
-    else launch_rerank_tile<2048>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, eps, d_stats, st);
+    if (nt.kcap <= 512) launch_rerank_tile<1024>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, st);
+    else launch_rerank_tile<2048>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, st);
 }
 
 // exact similarities of one user against everyone (out[user] = -inf): the fallback for rows whose

@@ -42,20 +42,31 @@ static constexpr int NBINS = 4096;
 static constexpr int TCOLS = SELECT_TCOLS;  // columns of the row held in LDS at a time (128 KiB)
 static constexpr int CPT = TCOLS / TPB;  // columns per thread per tile (32 = 4 groups of 8)
 static constexpr int NG = CPT / 8;
+static_assert(CPT <= 32, "the survivor mask of a thread is one 32-bit word");
 static constexpr int EMAX = 512;     // row positions whose tail entries (16 B each) are held in LDS at a time
+static constexpr bool PIPELINE_TAIL = false;  // request a tile's first pieces during the previous tile's select work (measured: no gain)
 static constexpr int PMAX = 2048;    // pieces per (chunk, tile) with a direct piece -> entry table in LDS
 static constexpr int MAXT = 8;       // tiles whose per-entry rater counts are packed into registers
 static constexpr int MAX_PER_THREAD = 16;  // provisional entries per thread in the final compaction
 static constexpr int TAIL_ILP = 16;        // 64-rater pieces a wave keeps in flight
 // the tail is accumulated in Q7.24 fixed point with integer LDS atomics (ds_add_u32; the float form
 // ds_add_f32 measured ~1.4x slower here): |sum| <= 1, each product is quantised with error <= 2^-25,
-// which the per-common-item term of row_eps covers
-static constexpr float TAIL_FIX = 16777216.0f;
+// which the per-common-item term of row_eps covers.  The rater-side factor comes as Q0.16 (4-byte tail
+// entries: half the L2/MALL traffic of an (id, fp32) pair); its rounding, <= 2^-16 |pre(u,i)| per product,
+// is added to the row's error band exactly (tail_eps).
+static constexpr float TAIL_FIX = 256.0f;  // x * 2^8 * (y * 2^16) = x y 2^24
 static constexpr float TAIL_UNFIX = 1.0f / 16777216.0f;
 
-// LDS cell of tile column c: the low and the high 4 columns of every group of 8 live in separate halves of the
-// array, so that the read-out (one thread = 8 consecutive columns) is two conflict-free 16-byte accesses
-__device__ __forceinline__ int32_t acc_index(int32_t c) { return (((c >> 3) << 2) | (c & 3)) + ((c & 4) ? TCOLS / 2 : 0); }
+// inclusive prefix sum over the 64 lanes of a wave with DPP row shifts / broadcasts (no LDS traffic)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return x;
+}
 
 __device__ __forceinline__ int sim_bin(float x) {
     int b = (int)floorf((x + 1.0f) * (NBINS / 2));
@@ -74,8 +85,8 @@ struct TailArgs {
     const double* s_pre;
     const int32_t* colmap;  // < 0: tail item
     const int64_t* i_ptr;   // item-major rows, raters ascending
-    const int32_t* it_user;
-    const float* it_pre;
+    const uint32_t* it_pack;  // LDS cell of the column inside its tile << 17 | Q0.16 value (prep.hip: k_item_major)
+    uint32_t pack_bytes;
     const uint32_t* it_tile;  // [I][tile_stride]: first entry of the item's list with user >= t * TCOLS
     int32_t tile_stride;
     int32_t has_tail;
@@ -157,9 +168,10 @@ template <class ST>
 __global__ void __launch_bounds__(TPB) k_tail_select(const ST* __restrict__ S, int64_t ld, int32_t n_rows,
                                                      const int32_t* __restrict__ row_user, TailArgs T, int32_t U,
                                                      int32_t kk, float eps_base, int32_t cap, int32_t* __restrict__ cand_idx,
-                                                     float* __restrict__ cand_approx, int32_t* __restrict__ cand_cnt) {
+                                                     float* __restrict__ cand_approx, int32_t* __restrict__ cand_cnt,
+                                                     float* __restrict__ cand_eps) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int32_t* itile = reinterpret_cast<int32_t*>(smem);            // [TCOLS] tail accumulator, Q7.24, swizzled (acc_index)
+    int32_t* itile = reinterpret_cast<int32_t*>(smem);            // [TCOLS] tail accumulator, Q7.24, cell layout of it_pack
     uint32_t* hist = reinterpret_cast<uint32_t*>(itile + TCOLS);  // [NBINS]
     float* e_x = reinterpret_cast<float*>(hist + NBINS);          // [EMAX] pre(u, item) * 2^24
     uint32_t* e_b = reinterpret_cast<uint32_t*>(e_x + EMAX);      // [EMAX] this tile's range of the item's rater list
@@ -167,10 +179,11 @@ __global__ void __launch_bounds__(TPB) k_tail_select(const ST* __restrict__ S, i
     uint32_t* e_ps = e_e + EMAX;                                  // [EMAX] exclusive prefix of the 64-rater piece counts
     int32_t* e_item = reinterpret_cast<int32_t*>(e_ps);           //   (aliased: the item of the entry, until its owner read it)
     uint16_t* piece_e = reinterpret_cast<uint16_t*>(e_ps + EMAX); // [PMAX] entry of every piece
-    __shared__ uint32_t wtot[TPB / 64];
-    __shared__ float s_thr;
-    __shared__ uint32_t s_count;
-    __shared__ int32_t s_ne;
+    // (no static __shared__: the accumulator must sit at LDS address 0, its cell addresses come straight out of it_pack)
+    uint32_t* wtot = reinterpret_cast<uint32_t*>(piece_e + PMAX); // [TPB / 64]
+    float& s_thr = *reinterpret_cast<float*>(wtot + TPB / 64);
+    uint32_t& s_count = wtot[TPB / 64 + 1];
+    int32_t& s_ne = *reinterpret_cast<int32_t*>(wtot + TPB / 64 + 2);
     const int32_t r = blockIdx.x;
     if (r >= n_rows) return;
 #ifdef KNNCF_SELECT_PROFILE
@@ -179,11 +192,10 @@ __global__ void __launch_bounds__(TPB) k_tail_select(const ST* __restrict__ S, i
     const int32_t u = row_user[r];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t ub = T.u_ptr[u], ue = T.u_ptr[u + 1];
-    const float eps = row_eps(eps_base, ue - ub);
     const ST* row = S + (int64_t)r * ld;
     int32_t* out_idx = cand_idx + (int64_t)r * cap;
     float* out_apx = cand_approx + (int64_t)r * cap;
-    // this thread's 32 columns of a tile: group j covers columns t0 + 8 (tid + 1024 j) .. + 7
+    // this thread's CPT columns of a tile: group j covers columns t0 + 8 (tid + TPB j) .. + 7
     Raw8<ST> raw[NG];
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
@@ -211,10 +223,24 @@ __global__ void __launch_bounds__(TPB) k_tail_select(const ST* __restrict__ S, i
             }
         }
     };
-    if (n_chunks == 1) {
-        collect(0);
-        __syncthreads();
+    // error of the Q0.16 rater-side factors: 2^-16 * sum over the row's tail entries of |pre(u, i)|, summed in a fixed
+    // order (position -> thread, then shuffles) so that the band is the same on every run
+    float tail_abs = 0.f;
+    if (n_chunks > 0) {
+        for (int64_t p = ub + threadIdx.x; p < ue; p += TPB)
+            if (T.colmap[T.s_col[p]] < 0) tail_abs += fabsf((float)T.s_pre[p]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tail_abs += __shfl_xor(tail_abs, o);
+        if (lane == 0) reinterpret_cast<float*>(wtot)[wave] = tail_abs;
     }
+    if (n_chunks == 1) collect(0);
+    __syncthreads();
+    if (n_chunks > 0) {
+        tail_abs = 0.f;
+        for (int w = 0; w < TPB / 64; ++w) tail_abs += reinterpret_cast<const float*>(wtot)[w];
+    }
+    const float eps = row_eps(eps_base, ue - ub) + tail_abs * (1.0001f / 65536.0f);
+    if (threadIdx.x == 0) cand_eps[r] = eps;
     const bool any_tail = n_chunks > 1 || (n_chunks == 1 && s_ne > 0);
     // single-chunk rows: thread e owns entry e for the whole row.  Its item's rater counts per tile (<= 32768 each)
     // are packed into registers, so the tile loop needs no global read for the ranges
@@ -238,10 +264,139 @@ __global__ void __launch_bounds__(TPB) k_tail_select(const ST* __restrict__ S, i
     }
     __syncthreads();  // also: every owner has read e_item before e_ps (its alias) is written
 
+    // ---- the tail machinery: setup (ranges, prefix, piece table) / window (piece descriptors of up to 64 pieces of
+    // this wave) / issue (TAIL_ILP piece loads) / apply (their LDS atomics) ---------------------------------------
+    constexpr int ILP = sizeof(ST) == 2 ? TAIL_ILP : TAIL_ILP / 2;  // fp32 panels hold twice the prefetch registers
+    uint32_t P = 0, p_lo = 0, p_hi = 0, n_here = 0;
+    int32_t ne = 0;
+    uint32_t d_q = 0, d_end = 0;
+    float d_x = 0.f;
+    uint32_t w[ILP];
+    auto setup = [&](int tile) {
+        ne = s_ne;
+        uint32_t np = 0;
+        if ((int32_t)threadIdx.x < ne) {
+            uint32_t qb, cnt;
+            if (reg_counts) {
+                const uint32_t w01 = (tile & 2) ? cw[1] : cw[0], w23 = (tile & 2) ? cw[3] : cw[2];
+                const uint32_t ww = (tile & 4) ? w23 : w01;
+                cnt = (ww >> (16 * (tile & 1))) & 0xffffu;
+                qb = cur_b;
+                cur_b += cnt;
+            } else {
+                const uint32_t* tb = (n_chunks > 1 ? T.it_tile + (int64_t)e_item[threadIdx.x] * T.tile_stride : my_tb) + tile;
+                qb = tb[0];
+                cnt = tb[1] - qb;
+            }
+            e_b[threadIdx.x] = qb;
+            e_e[threadIdx.x] = qb + cnt;
+            np = (cnt + 63u) >> 6;
+        }
+        const uint32_t incl = wave_incl_scan(np);
+        if (lane == 63 && wave < EMAX / 64) wtot[wave] = incl;
+        __syncthreads();
+        uint32_t off = 0;
+        P = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < EMAX / 64; ++w2) {
+            const uint32_t sw = wtot[w2];
+            P += sw;
+            if (w2 < wave) off += sw;
+        }
+        if ((int32_t)threadIdx.x < ne) {
+            const uint32_t excl = off + incl - np;
+            e_ps[threadIdx.x] = excl;
+            if (P <= PMAX)
+                for (uint32_t k2 = 0; k2 < np; ++k2) piece_e[excl + k2] = (uint16_t)threadIdx.x;
+        }
+        __syncthreads();
+        // the pieces are dealt evenly: wave w takes [p_lo, p_hi).  (wave-uniform values are moved to scalar registers
+        // explicitly: the loops below then run on the scalar unit and the lane broadcasts are v_readlane)
+        P = __builtin_amdgcn_readfirstlane(P);
+        ne = __builtin_amdgcn_readfirstlane(ne);
+        const uint32_t wv = __builtin_amdgcn_readfirstlane(wave);
+        p_lo = (uint32_t)(((uint64_t)P * wv) / (TPB / 64));
+        p_hi = (uint32_t)(((uint64_t)P * (wv + 1)) / (TPB / 64));
+    };
+    auto window = [&](uint32_t pw) {  // lane l looks up the entry of piece pw + l and keeps its range
+        n_here = min(64u, p_hi - pw);
+        d_q = 0; d_end = 0; d_x = 0.f;
+        if ((uint32_t)lane < n_here) {
+            const uint32_t p2 = pw + lane;
+            int32_t e;
+            if (P <= PMAX) {
+                e = piece_e[p2];
+            } else {  // largest e with e_ps[e] <= p2 (a non-empty entry, as p2 < P)
+                int32_t lo = 0, hi = ne - 1;
+                while (lo < hi) {
+                    const int32_t mid = (lo + hi + 1) >> 1;
+                    if (e_ps[mid] <= p2) lo = mid;
+                    else hi = mid - 1;
+                }
+                e = lo;
+            }
+            d_q = e_b[e] + ((p2 - e_ps[e]) << 6);
+            d_end = e_e[e];
+            d_x = e_x[e];
+        }
+    };
+    // the entries come through a buffer descriptor: 32-bit offsets, and a lane outside its piece gets offset ~0, which
+    // the range check answers with 0 — a word that adds nothing, so "w != 0" is the only predicate
+    const __amdgpu_buffer_rsrc_t pack_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(T.it_pack), 0, T.pack_bytes, 0x00020000);
+    auto issue = [&](uint32_t j0) {
+#pragma unroll
+        for (int j = 0; j < ILP; ++j) {
+            const int src = (int)min(j0 + j, 63u);  // wave-uniform
+            const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)d_q, src) + lane;
+            const uint32_t qend = (j0 + j < n_here) ? (uint32_t)__builtin_amdgcn_readlane((int)d_end, src) : 0u;
+#ifdef KNNCF_EXP_NOLOAD
+            w[j] = q < qend ? q * 2654435761u : 0u;
+#else
+            w[j] = __builtin_amdgcn_raw_buffer_load_b32(pack_rsrc, q < qend ? (int)(q << 2) : -1, 0, 0);
+#endif
+        }
+    };
+    auto apply = [&](uint32_t j0) {
+#pragma unroll
+        for (int j = 0; j < ILP; ++j) {
+            const float xf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d_x), (int)min(j0 + j, 63u)));
+            if (w[j] != 0u) {
+                const int32_t qv = ((int32_t)(w[j] << 15)) >> 15;  // sign-extended low 17 bits
+                atomicAdd(&itile[w[j] >> 17], (int32_t)(xf * (float)qv));  // truncation: < 2^-24, inside row_eps' per-item term
+            }
+        }
+    };
+    // everything after the first ILP pieces of the wave's first window (those are issued ahead, see below)
+    auto drain = [&](bool first_issued) {
+        bool skip = first_issued;
+        for (uint32_t pw = p_lo; pw < p_hi; pw += 64) {
+            if (!skip) window(pw);
+            for (uint32_t j0 = 0; j0 < n_here; j0 += ILP) {
+                if (!skip) issue(j0);
+                skip = false;
+                apply(j0);
+            }
+        }
+    };
+    const bool pipelined = PIPELINE_TAIL && any_tail && n_chunks == 1;
+    if (pipelined) {  // prologue: tile 0's first pieces are requested before the loop
+        setup(0);
+        n_here = 0;
+        if (p_lo < p_hi) {
+            window(p_lo);
+            issue(0);
+        }
+    }
     PH(0);  // preamble: collect, clears
     int tile_no = 0;
     for (int32_t t0 = 0; t0 < U; t0 += TCOLS, ++tile_no) {
-        if (any_tail) {
+        if (pipelined) {
+            // this tile's first ILP pieces per wave were requested during the previous tile's select work
+            drain(true);
+            PH(4);  // LDS atomics (+ loads beyond the first ILP pieces)
+            __syncthreads();
+            PH(5);  // wait for the other waves
+        } else if (any_tail) {
             for (int ch = 0; ch < n_chunks; ++ch) {
                 if (n_chunks > 1) {
                     __syncthreads();
@@ -250,109 +405,30 @@ __global__ void __launch_bounds__(TPB) k_tail_select(const ST* __restrict__ S, i
                     collect(ch);
                     __syncthreads();
                 }
-                const int32_t ne = s_ne;
-                // the entries' ranges inside this tile and the exclusive prefix of their piece counts
-                uint32_t np = 0;
-                if ((int32_t)threadIdx.x < ne) {
-                    uint32_t qb, cnt;
-                    if (reg_counts) {
-                        const uint32_t w01 = (tile_no & 2) ? cw[1] : cw[0], w23 = (tile_no & 2) ? cw[3] : cw[2];
-                        const uint32_t w = (tile_no & 4) ? w23 : w01;
-                        cnt = (w >> (16 * (tile_no & 1))) & 0xffffu;
-                        qb = cur_b;
-                        cur_b += cnt;
-                    } else {
-                        const uint32_t* tb = (n_chunks > 1 ? T.it_tile + (int64_t)e_item[threadIdx.x] * T.tile_stride : my_tb) + tile_no;
-                        qb = tb[0];
-                        cnt = tb[1] - qb;
-                    }
-                    e_b[threadIdx.x] = qb;
-                    e_e[threadIdx.x] = qb + cnt;
-                    np = (cnt + 63u) >> 6;
-                }
-                uint32_t incl = np;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const uint32_t up = __shfl_up(incl, o);
-                    if (lane >= o) incl += up;
-                }
-                if (lane == 63 && wave < EMAX / 64) wtot[wave] = incl;
+                setup(tile_no);
+                drain(false);
                 __syncthreads();
-                uint32_t off = 0, P = 0;
-#pragma unroll
-                for (int w = 0; w < EMAX / 64; ++w) {
-                    const uint32_t sw = wtot[w];
-                    P += sw;
-                    if (w < wave) off += sw;
-                }
-                if ((int32_t)threadIdx.x < ne) {
-                    const uint32_t excl = off + incl - np;
-                    e_ps[threadIdx.x] = excl;
-                    if (P <= PMAX)
-                        for (uint32_t k2 = 0; k2 < np; ++k2) piece_e[excl + k2] = (uint16_t)threadIdx.x;
-                }
-                __syncthreads();
-                PH(2);  // ranges + prefix scan
-                // pieces [p_lo, p_hi) of this wave, 64 at a time: lane l looks up the entry of piece pw + l and keeps its
-                // range; then the pieces' loads are issued TAIL_ILP deep
-                const uint32_t p_lo = (uint32_t)(((uint64_t)P * wave) / (TPB / 64));
-                const uint32_t p_hi = (uint32_t)(((uint64_t)P * (wave + 1)) / (TPB / 64));
-                for (uint32_t pw = p_lo; pw < p_hi; pw += 64) {
-                    const uint32_t n_here = min(64u, p_hi - pw);
-                    uint32_t d_q = 0, d_end = 0;
-                    float d_x = 0.f;
-                    if ((uint32_t)lane < n_here) {
-                        const uint32_t p = pw + lane;
-                        int32_t e;
-                        if (P <= PMAX) {
-                            e = piece_e[p];
-                        } else {  // largest e with e_ps[e] <= p (a non-empty entry, as p < P)
-                            int32_t lo = 0, hi = ne - 1;
-                            while (lo < hi) {
-                                const int32_t mid = (lo + hi + 1) >> 1;
-                                if (e_ps[mid] <= p) lo = mid;
-                                else hi = mid - 1;
-                            }
-                            e = lo;
-                        }
-                        d_q = e_b[e] + ((p - e_ps[e]) << 6);
-                        d_end = e_e[e];
-                        d_x = e_x[e];
-                    }
-                    PH(3);  // piece descriptors
-                    for (uint32_t j0 = 0; j0 < n_here; j0 += TAIL_ILP) {
-                        int32_t v[TAIL_ILP];
-                        float y[TAIL_ILP];
-#pragma unroll
-                        for (int j = 0; j < TAIL_ILP; ++j) {
-                            const int src = (int)min(j0 + j, 63u);
-                            const uint32_t q = (uint32_t)__shfl((int)d_q, src) + lane;
-                            const uint32_t qend = (j0 + j < n_here) ? (uint32_t)__shfl((int)d_end, src) : 0u;
-                            v[j] = -1;
-                            y[j] = 0.f;
-                            if (q < qend) {
-                                v[j] = T.it_user[q];
-                                y[j] = T.it_pre[q];
-                            }
-                        }
-#pragma unroll
-                        for (int j = 0; j < TAIL_ILP; ++j) {
-                            const float xf = __shfl(d_x, (int)min(j0 + j, 63u));
-                            if (v[j] >= 0) atomicAdd(&itile[acc_index(v[j] - t0)], __float2int_rn(xf * y[j]));
-                        }
-                    }
-                }
-                PH(4);  // piece loads + LDS atomics (this wave)
-                __syncthreads();
-                PH(5);  // wait for the other waves
             }
+        }
+        if (pipelined && t0 + TCOLS < U) {  // next tile's ranges, pieces and first loads: they fly during the select work
+            setup(tile_no + 1);
+            PH(2);
+            n_here = 0;
+            if (p_lo < p_hi) {
+                window(p_lo);
+                issue(0);
+            }
+            PH(3);
+        } else {
+            p_lo = p_hi = 0;
+            n_here = 0;
         }
         // the tile's panel entries (requested one tile ago) are needed only now; the next tile's are requested here,
         // so that they arrive behind the select work of this tile and the tail work of the next
         float sx[CPT];
 #pragma unroll
         for (int j = 0; j < NG; ++j) raw[j].unpack(&sx[8 * j]);
-        if (t0 + TCOLS < U) {  // request the next tile's panel entries now: they arrive behind this tile's work
+        if (t0 + TCOLS < U) {
 #pragma unroll
             for (int j = 0; j < NG; ++j) {
                 const int64_t v0 = (int64_t)t0 + TCOLS + 8 * (threadIdx.x + TPB * j);
@@ -372,7 +448,8 @@ __global__ void __launch_bounds__(TPB) k_tail_select(const ST* __restrict__ S, i
         PH(1);  // unpack + next tile's requests
         if (any_tail) {
             // read the accumulator out and clear it for the next tile (only this thread touches these cells between
-            // the barriers).  acc_index keeps both 16-byte halves of a group at a 16-byte lane stride: no bank conflicts
+            // the barriers; the scaling by 2^-24 is exact, so the fused multiply-add rounds like multiply + add).  The cell
+            // layout (prep.hip: it_pack) keeps both 16-byte halves of a group at a 16-byte lane stride: no bank conflicts
 #pragma unroll
             for (int j = 0; j < NG; ++j) {
                 const int32_t g = threadIdx.x + TPB * j;
@@ -381,10 +458,10 @@ __global__ void __launch_bounds__(TPB) k_tail_select(const ST* __restrict__ S, i
                 const int4 a = *lo4, b = *hi4;
                 *lo4 = make_int4(0, 0, 0, 0);
                 *hi4 = make_int4(0, 0, 0, 0);
-                sx[8 * j + 0] += (float)a.x * TAIL_UNFIX; sx[8 * j + 1] += (float)a.y * TAIL_UNFIX;
-                sx[8 * j + 2] += (float)a.z * TAIL_UNFIX; sx[8 * j + 3] += (float)a.w * TAIL_UNFIX;
-                sx[8 * j + 4] += (float)b.x * TAIL_UNFIX; sx[8 * j + 5] += (float)b.y * TAIL_UNFIX;
-                sx[8 * j + 6] += (float)b.z * TAIL_UNFIX; sx[8 * j + 7] += (float)b.w * TAIL_UNFIX;
+                sx[8 * j + 0] = __builtin_fmaf((float)a.x, TAIL_UNFIX, sx[8 * j + 0]); sx[8 * j + 1] = __builtin_fmaf((float)a.y, TAIL_UNFIX, sx[8 * j + 1]);
+                sx[8 * j + 2] = __builtin_fmaf((float)a.z, TAIL_UNFIX, sx[8 * j + 2]); sx[8 * j + 3] = __builtin_fmaf((float)a.w, TAIL_UNFIX, sx[8 * j + 3]);
+                sx[8 * j + 4] = __builtin_fmaf((float)b.x, TAIL_UNFIX, sx[8 * j + 4]); sx[8 * j + 5] = __builtin_fmaf((float)b.y, TAIL_UNFIX, sx[8 * j + 5]);
+                sx[8 * j + 6] = __builtin_fmaf((float)b.z, TAIL_UNFIX, sx[8 * j + 6]); sx[8 * j + 7] = __builtin_fmaf((float)b.w, TAIL_UNFIX, sx[8 * j + 7]);
             }
         }
         PH(6);  // read-out
@@ -399,10 +476,13 @@ __global__ void __launch_bounds__(TPB) k_tail_select(const ST* __restrict__ S, i
             // of any set of maxima over disjoint column sets is a lower bound of the kk-th largest value of the row,
             // and a tight one (the top values sit in different threads) — with one histogram atomic per maximum
             // instead of one per column.
-            if (kk <= TPB / 3) {
-                const float m = fmaxf(fmaxf(gm[0], gm[1]), fmaxf(gm[2], gm[3]));
-                if (m > -INFINITY) atomicAdd(&hist[sim_bin(m)], 1u);
-            } else if (kk <= (TPB * NG) / 3) {
+            if (kk <= (TCOLS / 32) / 3) {  // maxima over 4 groups = 32 columns: 1024 of them
+#pragma unroll
+                for (int j = 0; j < NG; j += 4) {
+                    const float m = fmaxf(fmaxf(gm[j], gm[j + 1]), fmaxf(gm[j + 2], gm[j + 3]));
+                    if (m > -INFINITY) atomicAdd(&hist[sim_bin(m)], 1u);
+                }
+            } else if (kk <= (TCOLS / 8) / 3) {
 #pragma unroll
                 for (int j = 0; j < NG; ++j)
                     if (gm[j] > -INFINITY) atomicAdd(&hist[sim_bin(gm[j])], 1u);
@@ -419,20 +499,43 @@ __global__ void __launch_bounds__(TPB) k_tail_select(const ST* __restrict__ S, i
         {
             // One fused pass with the threshold known so far (it can only rise; a stale one just lets a few more
             // provisional entries through): survivors enter the cumulative histogram and the provisional shortlist.
+            // Their slots come from ONE LDS atomic per wave (survivor bitmask per lane -> wave prefix sum), not one
+            // returning atomic per survivor: those round trips were the longest part of the tile.
             const float thr = s_thr;
+            uint32_t m = 0;
 #pragma unroll
             for (int j = 0; j < NG; ++j) {
                 if (gm[j] >= thr) {
-                    const int32_t v0 = t0 + 8 * (threadIdx.x + TPB * j);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const float x = sx[8 * j + i];
-                        if (x >= thr && x > -INFINITY) {
-                            atomicAdd(&hist[sim_bin(x)], 1u);
-                            const uint32_t pos = atomicAdd(&s_count, 1u);
-                            if (pos < (uint32_t)cap) {
-                                out_idx[pos] = v0 + i;
-                                out_apx[pos] = x;
+                        if (x >= thr && x > -INFINITY) m |= 1u << (8 * j + i);
+                    }
+                }
+            }
+            const uint32_t cnt = __popc(m);
+            const uint32_t incl = wave_incl_scan(cnt);
+            const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+            if (total > 0) {
+                uint32_t base = 0;
+                if (lane == 63) base = atomicAdd(&s_count, total);
+                base = __builtin_amdgcn_readlane(base, 63);
+                const uint32_t first = base + incl - cnt;
+#pragma unroll
+                for (int j = 0; j < NG; ++j) {
+                    if ((m >> (8 * j)) & 0xffu) {
+                        const int32_t v0 = t0 + 8 * (threadIdx.x + TPB * j);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int bit = 8 * j + i;
+                            if (m & (1u << bit)) {
+                                const float x = sx[bit];
+                                atomicAdd(&hist[sim_bin(x)], 1u);
+                                const uint32_t pos = first + __popc(m & ((1u << bit) - 1u));
+                                if (pos < (uint32_t)cap) {
+                                    out_idx[pos] = v0 + i;
+                                    out_apx[pos] = x;
+                                }
                             }
                         }
                     }
@@ -471,12 +574,25 @@ __global__ void __launch_bounds__(TPB) k_tail_select(const ST* __restrict__ S, i
     __syncthreads();
     if (threadIdx.x == 0) s_count = 0;
     __syncthreads();
+    {
+        uint32_t m = 0;
 #pragma unroll
-    for (int j = 0; j < MAX_PER_THREAD; ++j) {
-        if (kv[j] >= 0 && kx[j] >= thr) {
-            const uint32_t pos = atomicAdd(&s_count, 1u);
-            out_idx[pos] = kv[j];
-            out_apx[pos] = kx[j];
+        for (int j = 0; j < MAX_PER_THREAD; ++j)
+            if (kv[j] >= 0 && kx[j] >= thr) m |= 1u << j;
+        const uint32_t cnt = __popc(m);
+        const uint32_t incl = wave_incl_scan(cnt);
+        const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+        uint32_t base = 0;
+        if (lane == 63 && total > 0) base = atomicAdd(&s_count, total);
+        base = __builtin_amdgcn_readlane(base, 63);
+        const uint32_t first = base + incl - cnt;
+#pragma unroll
+        for (int j = 0; j < MAX_PER_THREAD; ++j) {
+            if (m & (1u << j)) {
+                const uint32_t pos = first + __popc(m & ((1u << j) - 1u));
+                out_idx[pos] = kv[j];
+                out_apx[pos] = kx[j];
+            }
         }
     }
     __syncthreads();
@@ -500,14 +616,14 @@ void select_profile_dump() {
 template <class ST>
 static void launch_tail_select_t(const TailArgs& T, const ST* S, int64_t lds, int32_t n_rows, const int32_t* d_row_user,
                                  int32_t U, int32_t kk, float eps, int32_t cap, int32_t* cand_idx, float* cand_approx,
-                                 int32_t* cand_cnt, hipStream_t st) {
-    const size_t smem = (size_t)TCOLS * 4 + (size_t)NBINS * 4 + (size_t)EMAX * 16 + (size_t)PMAX * 2;
+                                 int32_t* cand_cnt, float* cand_eps, hipStream_t st) {
+    const size_t smem = (size_t)TCOLS * 4 + (size_t)NBINS * 4 + (size_t)EMAX * 16 + (size_t)PMAX * 2 + (TPB / 64 + 4) * 4;
     static bool attr_set = false;
     if (!attr_set) {
         KN_HIP(hipFuncSetAttribute((const void*)k_tail_select<ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
-    k_tail_select<ST><<<n_rows, TPB, smem, st>>>(S, lds, n_rows, d_row_user, T, U, kk, eps, cap, cand_idx, cand_approx, cand_cnt);
+    k_tail_select<ST><<<n_rows, TPB, smem, st>>>(S, lds, n_rows, d_row_user, T, U, kk, eps, cap, cand_idx, cand_approx, cand_cnt, cand_eps);
     KN_HIP(hipGetLastError());
 #ifdef KNNCF_SELECT_PROFILE
     KN_HIP(hipStreamSynchronize(st));
@@ -517,7 +633,7 @@ static void launch_tail_select_t(const TailArgs& T, const ST* S, int64_t lds, in
 
 void launch_tail_select(const Train& tr, const int32_t* d_colmap, bool has_tail, const void* S, bool s_fp16, int64_t lds,
                         int32_t n_rows, const int32_t* d_row_user, int32_t k, float eps, int32_t cap,
-                        int32_t* cand_idx, float* cand_approx, int32_t* cand_cnt, hipStream_t st) {
+                        int32_t* cand_idx, float* cand_approx, int32_t* cand_cnt, float* cand_eps, hipStream_t st) {
     if (n_rows <= 0) return;
     KN_REQUIRE(cap <= TPB * MAX_PER_THREAD, KNNCF_E_INVALID, "select: shortlist store larger than the compaction window");
     const int32_t U = tr.U;
@@ -526,9 +642,9 @@ void launch_tail_select(const Train& tr, const int32_t* d_colmap, bool has_tail,
     KN_REQUIRE(!has_tail || tr.tile_stride == (int32_t)ceil_div(U, TCOLS) + 1, KNNCF_E_STATE, "select: tile table missing");
     static const bool debug_no_tail = getenv("KNNCF_DEBUG_NO_TAIL") != nullptr;  // timing experiments only: wrong results
     if (debug_no_tail) has_tail = false;
-    TailArgs T{tr.u_ptr.p, tr.s_col.p, tr.s_pre.p, d_colmap, tr.i_ptr.p, tr.it_user.p, tr.it_pre.p, tr.it_tile.p, tr.tile_stride, has_tail ? 1 : 0};
-    if (s_fp16) launch_tail_select_t(T, static_cast<const _Float16*>(S), lds, n_rows, d_row_user, U, kk, eps, cap, cand_idx, cand_approx, cand_cnt, st);
-    else launch_tail_select_t(T, static_cast<const float*>(S), lds, n_rows, d_row_user, U, kk, eps, cap, cand_idx, cand_approx, cand_cnt, st);
+    TailArgs T{tr.u_ptr.p, tr.s_col.p, tr.s_pre.p, d_colmap, tr.i_ptr.p, tr.it_pack.p, (uint32_t)(tr.n * 4), tr.it_tile.p, tr.tile_stride, has_tail ? 1 : 0};
+    if (s_fp16) launch_tail_select_t(T, static_cast<const _Float16*>(S), lds, n_rows, d_row_user, U, kk, eps, cap, cand_idx, cand_approx, cand_cnt, cand_eps, st);
+    else launch_tail_select_t(T, static_cast<const float*>(S), lds, n_rows, d_row_user, U, kk, eps, cap, cand_idx, cand_approx, cand_cnt, cand_eps, st);
 }
 
 }  // namespace knncf
