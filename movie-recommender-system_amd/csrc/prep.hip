@@ -283,7 +283,7 @@ static uint32_t read_status(PrepScratch& sc, hipStream_t st) {
 void prep_fit(Train& tr, PrepScratch& sc, int32_t shard_rank, int32_t shard_count, hipStream_t st) {
     const int64_t n = tr.n;
     KN_REQUIRE(n > 0, KNNCF_E_INVALID, "fit: empty training set");
-    KN_REQUIRE(n < (int64_t)0xffffffffll, KNNCF_E_UNSUPPORTED, "fit: more than 2^32-1 ratings");
+    KN_REQUIRE(n < (int64_t)1 << 29, KNNCF_E_UNSUPPORTED, "fit: more than 2^29-1 ratings (the kernels address the rating arrays with 32-bit byte offsets)");
     sc.status.ensure(4);
     KN_HIP(hipMemsetAsync(sc.status.p, 0, 4 * sizeof(uint32_t), st));
     sc.k32_a.ensure(n); sc.k32_b.ensure(n); sc.v32_a.ensure(n); sc.v32_b.ensure(n);

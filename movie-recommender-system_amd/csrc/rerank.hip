@@ -10,17 +10,21 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <stdio.h>
+#include <string.h>
+
 #include "engine.h"
 
 namespace knncf {
 
-static constexpr int TPB = 256;
+static constexpr int TPB = 512;
 
 struct Rows {
     const int64_t* u_ptr;
     const int32_t* s_col;
     const uint32_t* s_t;
     const double* s_pre;
+    uint32_t col_bytes, pre_bytes;  // buffer-descriptor extents of s_col / s_pre
 };
 
 // lower bound of `col` in s_col[lo, hi)
@@ -145,88 +149,144 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+#ifdef KNNCF_RERANK_PROFILE
+__device__ unsigned long long g_rphase[8];
+#define RPH(i) do { if (threadIdx.x == 0) { const long long now_ = clock64(); atomicAdd(&g_rphase[i], (unsigned long long)(now_ - ph_t)); ph_t = now_; } } while (0)
+#else
+#define RPH(i) do {} while (0)
+#endif
+#ifdef KNNCF_RERANK_PROFILE
+#define FOLD_T0() long long f_t0 = clock64()
+#define FOLD_T1() do { if (threadIdx.x == 0) atomicAdd(&g_rphase[5], (unsigned long long)(clock64() - f_t0)); } while (0)
+#else
+#define FOLD_T0() do {} while (0)
+#define FOLD_T1() do {} while (0)
+#endif
+
 // exact similarities of this wave's candidates (n_c <= 64); lane j returns candidate j's.
-// The candidates' rows form one stream of 64-entry pieces; PIPE pieces are always in flight (the loop
-// is bound by the latency of these L2/HBM reads, not by their volume).
-static constexpr int PIPE = 4;
+// The candidates' rows are read as ONE stream: position s of the stream belongs to candidate j with
+// cstart[j] <= s < cend[j] (per-wave arrays in LDS; each lane walks them forward as its positions grow by 64 per
+// piece), so every lane of every piece carries an entry whatever the row lengths are.  PIPE pieces are in flight;
+// they are consumed GRP at a time in stage order (bitmap words of all GRP pieces, then u's values, then the writes)
+// so that the dependent LDS round trips of different pieces overlap.  The loop is bound by instruction issue and
+// LDS latency, not by the volume read, so the per-piece instruction count is what is minimised here.
+// Hits are appended to the wave's product buffer in stream order (= candidate by candidate, items ascending); the
+// lane holding a candidate's FIRST entry records where that candidate's products start (cofs), which is all the
+// fold needs: candidate j's products are [cofs[j], cofs[j+1]).
+static constexpr int PIPE = 8;
+static constexpr int GRP = 4;
+static constexpr int WMETA = 256;  // per-wave LDS words: (cend, cbase)[64] | cofs[65]
+static constexpr uint32_t NOT_STARTED = 0xffffffffu;
+
+typedef __attribute__((address_space(3))) uint32_t* lds_u32;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef const __attribute__((address_space(3))) u32x2* lds_cu32x2;
+typedef __attribute__((address_space(3))) u32x2* lds_u32x2;
 
 template <class PreP>
-__device__ __forceinline__ double wave_sims(const Rows& R, lds_cu32 bits, lds_cu32 pref, PreP upre, int32_t ufirst,
-                                            int32_t ulast, lds_f64 wb, int32_t my_v, int n_c, int lane) {
+__device__ __forceinline__ double wave_sims(const Rows& R, lds_cu32x2 bp, PreP upre, int32_t nu, lds_f64 wb, lds_u32 meta,
+                                            int32_t my_v, int n_c, int lane) {
+    lds_u32x2 cpair = (lds_u32x2)meta;  // [64] (end of candidate j in the stream, entry of stream position 0 of j)
+    lds_u32 cofs = meta + 128;          // [65] first product of candidate j in the product buffer
     const bool have = lane < n_c;
-    const int64_t my_b = have ? R.u_ptr[my_v] : 0;
-    const int64_t my_e = have ? R.u_ptr[my_v + 1] : 0;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t my_b = have ? (uint32_t)R.u_ptr[my_v] : 0u;  // n < 2^29 (checked at fit)
+    const uint32_t my_len = have ? (uint32_t)R.u_ptr[my_v + 1] - my_b : 0u;
+    const uint32_t incl = wave_incl_scan(my_len);
+    const uint32_t E = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    {
+        u32x2 pr;
+        pr.x = incl;
+        pr.y = my_b - (incl - my_len);  // entry of stream position s: cbase[j] + s
+        cpair[lane] = pr;
+    }
+    cofs[lane] = NOT_STARTED;
+    if (lane == 0) cofs[64] = NOT_STARTED;
+    wave_sync();
+    const uint32_t NP = (E + 63u) >> 6;
     double acc = 0.0;
-    int32_t my_off = 0, my_cnt = 0, off = 0;
-    // fetch cursor (wave-uniform): candidate, piece start, row end
-    int fj = 0;
-    int64_t fbase = __shfl(my_b, 0), feb = __shfl(my_e, 0);
-    int pj[PIPE];        // candidate of the piece in slot d (n_c = empty slot)
-    int64_t pbase[PIPE], peb[PIPE];
-    int32_t pc[PIPE];
-    double py[PIPE];
+    uint32_t off = 0;
+    // stream cursor of this lane: candidate jf = [c_start, c_end), never moves backwards
+    int32_t jf = 0;
+    uint32_t c_start = 0, c_end, c_base;
+    {
+        const u32x2 p0 = cpair[0];
+        c_end = p0.x;
+        c_base = p0.y;
+    }
+    uint32_t pc[PIPE];
+    u32x2 py[PIPE];
+    uint32_t pfl[PIPE];  // bit 0: the entry exists, bit 1: it is the first entry of its candidate; bits 8..: candidate
+    // The loads go through buffer descriptors and are issued UNCONDITIONALLY (a lane past the stream's end uses an
+    // out-of-range offset and gets 0): with loads under a branch the compiler cannot count what is in flight and
+    // waits for everything (vmcnt(0)) before the first use, which serialises the whole pipeline.
+    const __amdgpu_buffer_rsrc_t col_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(R.s_col), 0, R.col_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t pre_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(R.s_pre), 0, R.pre_bytes, 0x00020000);
+    auto request = [&](int d, uint32_t p) {
+        const uint32_t s = (p << 6) + lane;
+        const bool valid = s < E;
+        if (valid) {
+            while (s >= c_end) {
+                c_start = c_end;
+                ++jf;
+                const u32x2 pr = cpair[jf];
+                c_end = pr.x;
+                c_base = pr.y;
+            }
+        }
+        const uint32_t q = valid ? c_base + s : 0x3fffffffu;  // -> byte offsets beyond both arrays
+#ifdef KNNCF_EXP_NOLOAD
+        pc[d] = (q * 2654435761u) >> 16;
+        py[d].x = q; py[d].y = 0x3ff00000u;
+#else
+        pc[d] = __builtin_amdgcn_raw_buffer_load_b32(col_rsrc, (int)(q << 2), 0, 0);  // (no use of the loaded values
+        py[d] = __builtin_amdgcn_raw_buffer_load_b64(pre_rsrc, (int)(q << 3), 0, 0);  //  here: a use is a wait)
+#endif
+        pfl[d] = valid ? (((uint32_t)jf << 8) | (s == c_start ? 3u : 1u)) : 0u;
+    };
+    auto fold = [&]() {  // lane j folds candidate j's products left: the reference's `.sum` order
+        FOLD_T0();
+        wave_sync();
+        const uint32_t o0 = min(cofs[lane], off), o1 = min(cofs[lane + 1], off);
+        for (uint32_t t = o0; t < o1; ++t) acc = acc + wb[t];
+        if (cofs[lane] != NOT_STARTED) cofs[lane] = 0;  // finished or in progress: whatever follows starts at 0
+        wave_sync();
+        off = 0;
+        FOLD_T1();
+    };
 #pragma unroll
-    for (int d = 0; d < PIPE; ++d) {
-        pj[d] = fj; pbase[d] = fbase; peb[d] = feb;
-        pc[d] = 0x7fffffff; py[d] = 0.0;
-        if (fj < n_c) {
-            const int64_t q = fbase + lane;
-            if (q < feb) { pc[d] = R.s_col[q]; py[d] = R.s_pre[q]; }
-            fbase += 64;
-            if (fbase >= feb) {
-                ++fj;
-                if (fj < n_c) { fbase = __shfl(my_b, fj); feb = __shfl(my_e, fj); }
+    for (int d = 0; d < PIPE; ++d) request(d, (uint32_t)d);
+    for (uint32_t p0 = 0; p0 < NP; p0 += PIPE) {
+#pragma unroll
+        for (int g = 0; g < PIPE; g += GRP) {
+            if (p0 + g < NP) {  // wave-uniform
+                if (off + 64 * GRP > WBUF) fold();
+                u32x2 wp[GRP];
+                unsigned long long mask[GRP];
+                double prod[GRP];
+#pragma unroll
+                for (int k = 0; k < GRP; ++k) wp[k] = bp[pc[g + k] >> 5];  // (an absent entry reads word 0: harmless)
+#pragma unroll
+                for (int k = 0; k < GRP; ++k) {
+                    const uint32_t c = pc[g + k];
+                    const bool hit = ((wp[k].x >> (c & 31u)) & pfl[g + k] & 1u) != 0u;
+                    mask[k] = __ballot(hit);
+                    // position of item c in u's row (for a miss: some position of the row, its value is not used)
+                    const int32_t idx = min((int32_t)(wp[k].y + __popc(wp[k].x & ((1u << (c & 31u)) - 1u))), nu - 1);
+                    prod[k] = upre[idx] * __hiloint2double((int)py[g + k].y, (int)py[g + k].x);
+                }
+#pragma unroll
+                for (int k = 0; k < GRP; ++k) {
+                    const uint32_t pos = off + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask[k], 0u));
+                    if ((mask[k] >> lane) & 1ull) wb[pos] = prod[k];
+                    if (pfl[g + k] & 2u) cofs[pfl[g + k] >> 8] = pos;  // this candidate's products start here
+                    off += (uint32_t)__popcll(mask[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < GRP; ++k) request(g + k, p0 + g + k + PIPE);
             }
         }
     }
-    while (pj[0] < n_c) {
-#pragma unroll
-        for (int d = 0; d < PIPE; ++d) {
-            const int j = pj[d];
-            if (j < n_c) {  // wave-uniform
-                if (off + 64 > WBUF) {  // fold what has been collected; partial candidates continue in `acc`
-                    wave_sync();
-                    for (int32_t t = 0; t < my_cnt; ++t) acc = acc + wb[my_off + t];
-                    wave_sync();
-                    off = 0; my_off = 0; my_cnt = 0;
-                }
-                const int32_t c_cur = pc[d];
-                const double y_cur = py[d];
-                if (pbase[d] == __shfl(my_b, j) && lane == j) my_off = off;  // candidate j's products start here
-                const int32_t cmin = __shfl(c_cur, 0);
-                const int32_t cmax = __shfl(c_cur, (int)(min(peb[d] - 1, pbase[d] + 63) - pbase[d]));
-                if (cmin <= ulast && cmax >= ufirst) {  // otherwise the piece lies outside u's item range
-                    const bool valid = c_cur != 0x7fffffff;
-                    const uint32_t word = valid ? bits[c_cur >> 5] : 0u;
-                    const bool hit = (word >> (c_cur & 31)) & 1u;
-                    const unsigned long long mask = __ballot(hit);
-                    if (hit) {
-                        const int32_t idx = (int32_t)pref[c_cur >> 5] + __popc(word & ((1u << (c_cur & 31)) - 1u));
-                        wb[off + __popcll(mask & lt_mask)] = upre[idx] * y_cur;
-                    }
-                    const int32_t n = __popcll(mask);
-                    if (lane == j) my_cnt += n;
-                    off += n;
-                }
-            }
-            // refill the slot with the next piece of the stream
-            pj[d] = fj; pbase[d] = fbase; peb[d] = feb;
-            pc[d] = 0x7fffffff; py[d] = 0.0;
-            if (fj < n_c) {
-                const int64_t q = fbase + lane;
-                if (q < feb) { pc[d] = R.s_col[q]; py[d] = R.s_pre[q]; }
-                fbase += 64;
-                if (fbase >= feb) {
-                    ++fj;
-                    if (fj < n_c) { fbase = __shfl(my_b, fj); feb = __shfl(my_e, fj); }
-                }
-            }
-        }
-    }
-    wave_sync();
-    for (int32_t t = 0; t < my_cnt; ++t) acc = acc + wb[my_off + t];
-    wave_sync();
+    fold();
     return acc;
 }
 
@@ -244,30 +304,33 @@ __global__ void __launch_bounds__(TPB) k_rerank(Rows R, const int64_t* __restric
     double* upre = ssim + TILE;                                // [UPRE_LDS]
     double* wbuf = upre + UPRE_LDS;                            // [4][WBUF]
     int32_t* sidx = reinterpret_cast<int32_t*>(wbuf + (TPB / 64) * WBUF);  // [TILE]
-    uint32_t* bits = reinterpret_cast<uint32_t*>(sidx + TILE);  // [words]
-    uint32_t* pref = bits + words;                              // [words]
+    u32x2* bp = reinterpret_cast<u32x2*>(sidx + TILE);         // [words] (bitmap word of u's items, items of u before it)
+    uint32_t* wmeta = reinterpret_cast<uint32_t*>(bp + words);  // [TPB / 64][WMETA]
     const int32_t r = blockIdx.x;
     if (r >= n_rows) return;
     const int32_t cnt = cand_cnt[r];
     if (cnt > cap) return;  // overflow: the exact fallback redoes this row
+#ifdef KNNCF_RERANK_PROFILE
+    long long ph_t = clock64();
+#endif
     const int32_t u = row_user[r];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t ub = R.u_ptr[u];
     const int32_t nu = (int32_t)(R.u_ptr[u + 1] - ub);
     const bool pre_lds = nu <= UPRE_LDS;
     // u's items as a bitmap + exclusive prefix popcounts
-    for (int32_t w = threadIdx.x; w < words; w += TPB) bits[w] = 0u;
+    for (int32_t w = threadIdx.x; w < words; w += TPB) bp[w] = u32x2{0u, 0u};
     __syncthreads();
     for (int32_t j = threadIdx.x; j < nu; j += TPB) {
         const int32_t c = R.s_col[ub + j];
-        atomicOr(&bits[c >> 5], 1u << (c & 31));
+        atomicOr(reinterpret_cast<uint32_t*>(bp) + 2 * (c >> 5), 1u << (c & 31));
         if (pre_lds) upre[j] = R.s_pre[ub + j];
     }
     __syncthreads();
     const int32_t per = (words + TPB - 1) / TPB;
     const int32_t w0 = min(words, (int32_t)threadIdx.x * per), w1 = min(words, w0 + per);
     uint32_t mine = 0;
-    for (int32_t w = w0; w < w1; ++w) mine += __popc(bits[w]);
+    for (int32_t w = w0; w < w1; ++w) mine += __popc(bp[w].x);
     part[threadIdx.x] = mine;
     __syncthreads();
     for (int o = 1; o < TPB; o <<= 1) {  // inclusive prefix scan
@@ -278,24 +341,30 @@ __global__ void __launch_bounds__(TPB) k_rerank(Rows R, const int64_t* __restric
     }
     uint32_t run = part[threadIdx.x] - mine;
     for (int32_t w = w0; w < w1; ++w) {
-        pref[w] = run;
-        run += __popc(bits[w]);
+        bp[w].y = run;
+        run += __popc(bp[w].x);
     }
-    const int32_t ufirst = R.s_col[ub], ulast = R.s_col[ub + nu - 1];
     const int64_t seq_u = seq[u];
     const float eps = cand_eps[r];  // the band select.hip used for this row (KNNCF_FLAG_VERIFY_BOUND)
     const int32_t* my_cand = cand_idx + (int64_t)r * cap;
     lds_f64 wb = (lds_f64)(wbuf + wave * WBUF);
+    lds_u32 meta = (lds_u32)(wmeta + wave * WMETA);
     double worst = -1.0;
     int64_t row_entries = 0;
     int32_t best = 0, pos = 0;
     __syncthreads();
+    RPH(0);  // bitmap + prefix
     do {
         const int32_t take = min(TILE - best, cnt - pos);
         int32_t m = 1;
         while (m < best + take) m <<= 1;
-        for (int32_t c0 = wave * 64; c0 < take; c0 += TPB) {  // 64 candidates per wave per trip
-            const int n_c = min(64, take - c0);
+        // the candidates of a trip (up to 64 per wave) are dealt evenly to the waves
+        for (int32_t t0 = 0; t0 < take; t0 += TPB) {
+            const int32_t in_trip = min(TPB, take - t0);
+            const int32_t per = (in_trip + TPB / 64 - 1) / (TPB / 64);
+            const int32_t c0 = t0 + wave * per;
+            const int n_c = max(0, min(per, t0 + in_trip - c0));
+            if (n_c == 0) continue;
             const int32_t v = (lane < n_c) ? my_cand[pos + c0 + lane] : 0;
             double s;
             // Set1..Set4 iterate in file order and the memo history matters (N2, N6): scalar path
@@ -303,8 +372,8 @@ __global__ void __launch_bounds__(TPB) k_rerank(Rows R, const int64_t* __restric
             row_entries += len_v;  // algorithmic traffic of this kernel: the candidates' rows (12 B per entry)
             const bool small_v = (lane < n_c) && (len_v <= 4);
             if (nu > 4 && !__any(small_v)) {
-                s = pre_lds ? wave_sims(R, (lds_cu32)bits, (lds_cu32)pref, (lds_cf64)upre, ufirst, ulast, wb, v, n_c, lane)
-                            : wave_sims(R, (lds_cu32)bits, (lds_cu32)pref, R.s_pre + ub, ufirst, ulast, wb, v, n_c, lane);
+                s = pre_lds ? wave_sims(R, (lds_cu32x2)bp, (lds_cf64)upre, nu, wb, meta, v, n_c, lane)
+                            : wave_sims(R, (lds_cu32x2)bp, R.s_pre + ub, nu, wb, meta, v, n_c, lane);
             } else {
                 s = (lane < n_c) ? pair_sim(R, u, v, seq_u, seq[v]) : 0.0;
             }
@@ -314,11 +383,13 @@ __global__ void __launch_bounds__(TPB) k_rerank(Rows R, const int64_t* __restric
                 if (cand_approx) worst = fmax(worst, fabs((double)cand_approx[(int64_t)r * cap + pos + c0 + lane] - s) - (double)eps);
             }
         }
+        RPH(1);  // exact similarities (this wave)
         for (int32_t c = take + threadIdx.x; c < m - best; c += TPB) {
             ssim[best + c] = -INFINITY;
             sidx[best + c] = 0x7fffffff;
         }
         __syncthreads();
+        RPH(2);  // wait for the other waves
         for (int32_t size = 2; size <= m; size <<= 1) {
             for (int32_t stride = size >> 1; stride > 0; stride >>= 1) {
                 for (int32_t t = threadIdx.x; t < (m >> 1); t += TPB) {
@@ -338,6 +409,7 @@ __global__ void __launch_bounds__(TPB) k_rerank(Rows R, const int64_t* __restric
         }
         best = min(kk, best + take);
         pos += take;
+        RPH(3);  // sort
     } while (pos < cnt);
     for (int o = 32; o > 0; o >>= 1) row_entries += __shfl_xor(row_entries, o);
     if (lane == 0 && row_entries > 0) atomicAdd(reinterpret_cast<unsigned long long*>(stats) + 1, (unsigned long long)row_entries);
@@ -355,7 +427,23 @@ __global__ void __launch_bounds__(TPB) k_rerank(Rows R, const int64_t* __restric
         nbr_sim[(int64_t)u * kcap + j] = ssim[j];
     }
     if (threadIdx.x == 0) nbr_cnt[u] = best;
+    RPH(4);  // output
 }
+
+#ifdef KNNCF_RERANK_PROFILE
+static void rerank_profile_dump() {
+    unsigned long long h[8];
+    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_rphase), sizeof(h));
+    unsigned long long tot = 0;
+    for (int i = 0; i < 8; ++i) tot += h[i];
+    fprintf(stderr, "[rerank profile] total %.3e cycles:", (double)tot);
+    for (int i = 0; i <= 4; ++i) fprintf(stderr, " p%d %.1f%%", i, 100.0 * (double)h[i] / (double)(tot - h[5]));
+    fprintf(stderr, " | folds inside p1: %.1f%%", 100.0 * (double)h[5] / (double)(tot - h[5]));
+    fprintf(stderr, "\n");
+    memset(h, 0, sizeof(h));
+    hipMemcpyToSymbol(HIP_SYMBOL(g_rphase), h, sizeof(h));
+}
+#endif
 
 template <int TILE>
 static void launch_rerank_tile(const Rows& R, const Train& tr, NeighborTable& nt, int32_t n_rows, const int32_t* d_row_user,
@@ -363,7 +451,7 @@ static void launch_rerank_tile(const Rows& R, const Train& tr, NeighborTable& nt
                                const float* cand_eps, double* d_stats, hipStream_t st) {
     const int32_t words = (int32_t)ceil_div(tr.I, 32);
     const size_t smem = (size_t)TILE * 8 + (size_t)UPRE_LDS * 8 + (size_t)(TPB / 64) * WBUF * 8 + (size_t)TILE * 4 +
-                        (size_t)words * 8;
+                        (size_t)words * 8 + (size_t)(TPB / 64) * WMETA * 4;
     KN_REQUIRE(smem <= 160 * 1024 - 2048, KNNCF_E_UNSUPPORTED, "re-rank: item bitmap does not fit in LDS (too many items)");
     static size_t attr = 0;
     if (smem > attr) {
@@ -373,6 +461,10 @@ static void launch_rerank_tile(const Rows& R, const Train& tr, NeighborTable& nt
     k_rerank<TILE><<<n_rows, TPB, smem, st>>>(R, nt.seq.p, n_rows, d_row_user, cap, cand_idx, cand_approx, cand_cnt, nt.kcap,
                                               nt.kcap, nt.idx.p, nt.sim.p, nt.cnt.p, cand_eps, d_stats, words);
     KN_HIP(hipGetLastError());
+#ifdef KNNCF_RERANK_PROFILE
+    KN_HIP(hipStreamSynchronize(st));
+    rerank_profile_dump();
+#endif
 }
 
 void launch_rerank(const Train& tr, NeighborTable& nt, int32_t n_rows, const int32_t* d_row_user, int32_t cap,
@@ -380,7 +472,7 @@ void launch_rerank(const Train& tr, NeighborTable& nt, int32_t n_rows, const int
                    double* d_stats, bool verify, hipStream_t st) {
     if (n_rows <= 0) return;
     KN_REQUIRE(nt.kcap <= 1024, KNNCF_E_UNSUPPORTED, "k > 1024 is not supported by the re-rank kernel yet");
-    Rows R{tr.u_ptr.p, tr.s_col.p, tr.s_t.p, tr.s_pre.p};
+    Rows R{tr.u_ptr.p, tr.s_col.p, tr.s_t.p, tr.s_pre.p, (uint32_t)(tr.n * 4), (uint32_t)(tr.n * 8)};
     const float* apx = verify ? cand_approx : nullptr;
     if (nt.kcap <= 512) launch_rerank_tile<1024>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, st);
     else launch_rerank_tile<2048>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, st);
@@ -397,7 +489,7 @@ __global__ void k_exact_row(Rows R, const int64_t* __restrict__ seq, int32_t U, 
 
 void launch_exact_row(const Train& tr, const NeighborTable& nt, int32_t user, int64_t user_seq, double* d_out,
                       hipStream_t st) {
-    Rows R{tr.u_ptr.p, tr.s_col.p, tr.s_t.p, tr.s_pre.p};
+    Rows R{tr.u_ptr.p, tr.s_col.p, tr.s_t.p, tr.s_pre.p, (uint32_t)(tr.n * 4), (uint32_t)(tr.n * 8)};
     k_exact_row<<<(unsigned)ceil_div(tr.U, TPB), TPB, 0, st>>>(R, nt.seq.p, tr.U, user, user_seq, d_out);
     KN_HIP(hipGetLastError());
 }
@@ -407,7 +499,7 @@ __global__ void k_exact_pair(Rows R, int32_t u, int32_t v, double* __restrict__ 
 }
 
 void launch_exact_pair(const Train& tr, int32_t u, int32_t v, double* d_out, hipStream_t st) {
-    Rows R{tr.u_ptr.p, tr.s_col.p, tr.s_t.p, tr.s_pre.p};
+    Rows R{tr.u_ptr.p, tr.s_col.p, tr.s_t.p, tr.s_pre.p, (uint32_t)(tr.n * 4), (uint32_t)(tr.n * 8)};
     k_exact_pair<<<1, 64, 0, st>>>(R, u, v, d_out);
     KN_HIP(hipGetLastError());
 }

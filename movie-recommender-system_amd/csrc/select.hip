@@ -57,17 +57,6 @@ static constexpr int TAIL_ILP = 16;        // 64-rater pieces a wave keeps in fl
 static constexpr float TAIL_FIX = 256.0f;  // x * 2^8 * (y * 2^16) = x y 2^24
 static constexpr float TAIL_UNFIX = 1.0f / 16777216.0f;
 
-// inclusive prefix sum over the 64 lanes of a wave with DPP row shifts / broadcasts (no LDS traffic)
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
-    return x;
-}
-
 __device__ __forceinline__ int sim_bin(float x) {
     int b = (int)floorf((x + 1.0f) * (NBINS / 2));
     return min(max(b, 0), NBINS - 1);
