@@ -448,7 +448,16 @@ void run_predict(knncf_handle* h, int predictor, const int32_t* d_users, const i
     {
         Stage s(h, &h->tm.predict_ms);
         double* pred = d_pred_out ? d_pred_out : h->t_pred.p;
-        launch_predict(tr, &h->nt, kind, n, h->t_du.p, h->t_di.p, d_ratings, nullptr, pred, h->t_err.p, h->t_owned.p,
+        const uint32_t* d_order = nullptr;
+        const bool by_item = tr.ib_words > 0 && tr.ib_words * 12 <= 48 * 1024;
+        if (kind == KNNCF_PRED_KNN) {  // rows sorted by item (the item's rater bitmap lives in LDS) or else by user
+            PrepScratch& sc = h->prep;
+            sc.k64_a.ensure(n); sc.k64_b.ensure(n); sc.v32_a.ensure(n); sc.v32_b.ensure(n);
+            launch_user_keys(n, by_item ? h->t_di.p : h->t_du.p, sc.k64_a.p, sc.v32_a.p, st);
+            sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.v32_a.p, sc.v32_b.p, n, 32, st);
+            d_order = sc.v32_b.p;
+        }
+        launch_predict(tr, &h->nt, kind, n, h->t_du.p, h->t_di.p, d_ratings, d_order, by_item, pred, h->t_err.p, h->t_owned.p,
                        h->cfg.shard_rank == 0, st);
         if (sum_abs_err || count) {
             const int32_t nb = 1024;

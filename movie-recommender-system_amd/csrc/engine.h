@@ -149,8 +149,10 @@ void launch_exact_pair(const Train& tr, int32_t u, int32_t v, double* d_out, hip
 // skipped (unknown users belong to shard 0).  d_abs_err[t] = |r - p| or 0 for skipped rows.
 void launch_predict(const Train& tr, const NeighborTable* nt, int predictor, int64_t n,
                     const int32_t* d_du, const int32_t* d_di, const double* d_ratings,
-                    const uint32_t* d_order, double* d_pred, double* d_abs_err, uint8_t* d_owned,
+                    const uint32_t* d_order, bool order_by_item, double* d_pred, double* d_abs_err, uint8_t* d_owned,
                     bool unknown_users_owned, hipStream_t st);
+// (key, value) = (dense user or 2^32-1, row) of every test row: sorted, it is the d_order of the grouped kNN kernel
+void launch_user_keys(int64_t n, const int32_t* d_du, uint64_t* d_key, uint32_t* d_val, hipStream_t st);
 // deterministic fixed-shape reduction: sum of d_abs_err and count of d_owned
 void launch_reduce_err(const double* d_abs_err, const uint8_t* d_owned, int64_t n, double* d_partials,
                        int64_t* d_counts, int32_t n_blocks, hipStream_t st);
