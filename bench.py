@@ -163,7 +163,7 @@ def main():
         launches = max(1, tm["gemm_launches"])  # every per-row-block kernel is launched once per GEMM launch
         k = args.k
 
-        def roof(name, bound, ms, work, peak, unit, note):
+        def roof(name, bound, ms, work, peak, unit, note, launches=launches):
             """achieved = ALGORITHMIC work per launch / average launch duration (HIP events on the kernel's stream)"""
             s_per_launch = ms / launches / 1e3
             ach = (work / launches) / s_per_launch / 1e12 if s_per_launch > 0 else 0.0
@@ -180,9 +180,9 @@ def main():
                                   "panel entry size (2 B fp16 / 4 B fp32) * rows * U, read once + 4 B per tail pair product (packed column | Q0.16 value)"),
             "k_rerank": roof("k_rerank (exact fp64 re-rank + top-k)", "hbm", tm["rerank_ms"], tm["rerank_row_bytes"],
                              HBM_PEAK_TBPS, "TB/s", "12 B * ratings of every shortlisted candidate"),
-            "k_predict_knn": roof("k_predict_knn (weighted-sum prediction + MAE)", "hbm", tm["predict_ms"] * launches / steps,
-                                  12.0 * k * n_test * steps * launches / steps, HBM_PEAK_TBPS, "TB/s",
-                                  "12 * k B per prediction (SURVEY 8d)"),
+            "k_predict_knn": roof("k_predict_knn_items (weighted-sum prediction + MAE; the stage also holds the id lookup and the row sort)",
+                                  "hbm", tm["predict_ms"], 12.0 * k * n_test * steps, HBM_PEAK_TBPS, "TB/s",
+                                  "12 * k B per prediction (SURVEY 8d)", launches=steps),
         }
         kernels["k_gemm_nt_bf16"]["executed_tflops"] = (tm["gemm_flops_executed"] / launches) / (tm["gemm_ms"] / launches / 1e3) / 1e12 if tm["gemm_ms"] > 0 else 0.0
         stage_of = {"k_gemm_nt_bf16": "gemm_ms", "k_tail_select": "select_ms", "k_rerank": "rerank_ms", "k_predict_knn": "predict_ms"}

@@ -12,7 +12,7 @@ namespace knncf {
 typedef __bf16 bf16_t;
 
 // columns of a similarity row that select.hip holds in LDS at a time (prep.hip tabulates the tile crossings)
-static constexpr int SELECT_TCOLS = 32768;  // 2^15: it_pack keeps the column inside its tile in 15 bits
+static constexpr int SELECT_TCOLS = 16384;  // <= 2^15: it_pack keeps the LDS cell of the column inside its tile in 15 bits
 
 // ---- sort_util.hip (rocPRIM device radix sort / unique; K0 plumbing only) ---------------
 struct SortWorkspace {

@@ -1,14 +1,14 @@
 // select.hip — K5 sparse tail + K6 top-k neighbour select, fused per similarity row.
 //
 // The dense MFMA GEMM (gemm.hip) leaves S[u][v] = sum over the H most-rated items (fp16 or fp32
-// storage).  For row u this kernel (one 1024-thread workgroup per row) walks the row ONCE, a column tile
-// (32 768 columns = 128 KiB of LDS) at a time; the panel entries of tile t+1 are requested before tile t is
+// storage).  For row u this kernel (one 512-thread workgroup per row, two per CU) walks the row ONCE, a column tile
+// (16 384 columns = 64 KiB of LDS) at a time; the panel entries of tile t+1 are requested before tile t is
 // processed:
 //   1. SPARSE TAIL: for every tail item i rated by u and every rater v of i inside the tile,
 //      pre(u,i) * pre(v,i) is accumulated in Q7.24 fixed point with integer LDS atomics.  The rater lists
 //      are sorted by user and prep.hip tabulates where each list crosses a tile boundary (it_tile), so the
 //      tile's work is a set of [begin, end) ranges; they are cut into 64-rater pieces and the pieces are
-//      dealt evenly to the 16 waves (a prefix sum over the entries), several pieces in flight per wave;
+//      dealt evenly to the 8 waves (a prefix sum over the entries), several pieces in flight per wave;
 //   2. the tile's final values S + tail stay in registers and enter a cumulative 4096-bin LDS histogram;
 //      the bin holding the k-th largest value SEEN SO FAR gives a threshold that can only rise as more
 //      columns are seen, so every v of the tile with value >= (bin lower edge - 2 eps) is appended to a
@@ -34,20 +34,20 @@ __device__ unsigned long long g_phase[16];
 #define PH(i) do {} while (0)
 #endif
 
-// One 1024-thread workgroup per CU with the largest tile that fits.  Measured alternative: two 512-thread
-// workgroups per CU with 48 KiB tiles (twice as many tiles per row) ran 1.7x SLOWER — the cost is per tile
-// (barrier-separated phases), so fewer, larger tiles win.
-static constexpr int TPB = 1024;
-static constexpr int NBINS = 4096;
-static constexpr int TCOLS = SELECT_TCOLS;  // columns of the row held in LDS at a time (128 KiB)
+// Two 512-thread workgroups per CU, 16 384-column tiles (64 KiB each): the phases of a tile are separated by
+// barriers and neither workgroup can fill the CU alone; one 1024-thread workgroup with 32 768-column tiles measured
+// 10 % slower (and a 48 KiB-tile variant of an earlier version of this kernel 1.7x slower: tiles cost per tile).
+// __launch_bounds__(2 * TPB) caps the kernel at 128 VGPRs so that both workgroups fit.
+static constexpr int TPB = 512;
+static constexpr int NBINS = 2048;
+static constexpr int TCOLS = SELECT_TCOLS;  // columns of the row held in LDS at a time (64 KiB)
 static constexpr int CPT = TCOLS / TPB;  // columns per thread per tile (32 = 4 groups of 8)
 static constexpr int NG = CPT / 8;
 static_assert(CPT <= 32, "the survivor mask of a thread is one 32-bit word");
-static constexpr int EMAX = 512;     // row positions whose tail entries (16 B each) are held in LDS at a time
+static constexpr int EMAX = 256;     // row positions whose tail entries (16 B each) are held in LDS at a time
 static constexpr bool PIPELINE_TAIL = false;  // request a tile's first pieces during the previous tile's select work (measured: no gain)
-static constexpr int PMAX = 2048;    // pieces per (chunk, tile) with a direct piece -> entry table in LDS
-static constexpr int MAXT = 8;       // tiles whose per-entry rater counts are packed into registers
-static constexpr int MAX_PER_THREAD = 16;  // provisional entries per thread in the final compaction
+static constexpr int PMAX = 1024;    // pieces per (chunk, tile) with a direct piece -> entry table in LDS
+static constexpr int MAXT = 16;      // tiles whose per-entry rater counts are packed into registers
 static constexpr int TAIL_ILP = 16;        // 64-rater pieces a wave keeps in flight
 // the tail is accumulated in Q7.24 fixed point with integer LDS atomics (ds_add_u32; the float form
 // ds_add_f32 measured ~1.4x slower here): |sum| <= 1, each product is quantised with error <= 2^-25,
@@ -57,8 +57,12 @@ static constexpr int TAIL_ILP = 16;        // 64-rater pieces a wave keeps in fl
 static constexpr float TAIL_FIX = 256.0f;  // x * 2^8 * (y * 2^16) = x y 2^24
 static constexpr float TAIL_UNFIX = 1.0f / 16777216.0f;
 
+// The histogram covers [HIST_LO, HIST_LO + 1) with NBINS bins of width 1/NBINS; values outside land in the end
+// bins.  (A k-th largest value below HIST_LO puts the threshold in bin 0 = "everything qualifies" and the row takes
+// the exact fallback; one above the range only loosens the threshold to the top bin's edge.)
+static constexpr float HIST_LO = -0.125f;
 __device__ __forceinline__ int sim_bin(float x) {
-    int b = (int)floorf((x + 1.0f) * (NBINS / 2));
+    int b = (int)floorf((x - HIST_LO) * (float)NBINS);
     return min(max(b, 0), NBINS - 1);
 }
 
@@ -116,7 +120,7 @@ __device__ __forceinline__ void block_threshold(const uint32_t* hist, uint32_t* 
         }
         const int b = threadIdx.x * PER + j;
         // every value in bin b is >= its lower edge (up to one float rounding of x + 1)
-        const float edge = (float)b / (float)(NBINS / 2) - 1.0f;
+        const float edge = (float)b / (float)NBINS + HIST_LO;
         *s_thr = (b == 0) ? -INFINITY : edge - 2.0f * eps - 1e-6f;
     }
     __syncthreads();
@@ -154,7 +158,7 @@ struct Raw8<_Float16> {
 };
 
 template <class ST>
-__global__ void __launch_bounds__(TPB) k_tail_select(const ST* __restrict__ S, int64_t ld, int32_t n_rows,
+__global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ S, int64_t ld, int32_t n_rows,
                                                      const int32_t* __restrict__ row_user, TailArgs T, int32_t U,
                                                      int32_t kk, float eps_base, int32_t cap, int32_t* __restrict__ cand_idx,
                                                      float* __restrict__ cand_approx, int32_t* __restrict__ cand_cnt,
@@ -267,8 +271,9 @@ __global__ void __launch_bounds__(TPB) k_tail_select(const ST* __restrict__ S, i
         if ((int32_t)threadIdx.x < ne) {
             uint32_t qb, cnt;
             if (reg_counts) {
-                const uint32_t w01 = (tile & 2) ? cw[1] : cw[0], w23 = (tile & 2) ? cw[3] : cw[2];
-                const uint32_t ww = (tile & 4) ? w23 : w01;
+                uint32_t ww = cw[0];
+#pragma unroll
+                for (int t2 = 1; t2 < MAXT / 2; ++t2) ww = ((tile >> 1) == t2) ? cw[t2] : ww;
                 cnt = (ww >> (16 * (tile & 1))) & 0xffffu;
                 qb = cur_b;
                 cur_b += cnt;
@@ -376,6 +381,58 @@ __global__ void __launch_bounds__(TPB) k_tail_select(const ST* __restrict__ S, i
             issue(0);
         }
     }
+    // In-place compaction of the provisional list by a threshold, staged through LDS in chunks (the tail accumulator
+    // is idle — and all zero — between tiles; it is zeroed again afterwards).  Survivors of a chunk are appended to
+    // the scratch with one LDS atomic per wave and copied back behind the survivors of the earlier chunks.
+    auto compact = [&](float thr) {
+        constexpr uint32_t CH = TCOLS / 2;
+        int32_t* sc_idx = itile;
+        float* sc_apx = reinterpret_cast<float*>(itile + CH);
+        uint32_t& s_cc = wtot[TPB / 64 + 3];
+        const uint32_t prov = s_count;
+        uint32_t kept = 0;
+        for (uint32_t base = 0; base < prov; base += CH) {
+            const uint32_t n_chunk = min(CH, prov - base);
+            if (threadIdx.x == 0) s_cc = 0;
+            __syncthreads();
+            for (uint32_t i0 = 0; i0 < n_chunk; i0 += TPB) {
+                const uint32_t i = i0 + threadIdx.x;
+                int32_t v = 0;
+                float x = -INFINITY;
+                if (i < n_chunk) {
+                    v = out_idx[base + i];
+                    x = out_apx[base + i];
+                }
+                const bool keep = x >= thr && i < n_chunk;
+                const unsigned long long km = __ballot(keep);
+                if (km) {
+                    uint32_t wbase = 0;
+                    if (lane == 0) wbase = atomicAdd(&s_cc, (uint32_t)__popcll(km));
+                    wbase = __builtin_amdgcn_readlane(wbase, 0);
+                    if (keep) {
+                        const uint32_t pos = wbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+                        sc_idx[pos] = v;
+                        sc_apx[pos] = x;
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t cc = s_cc;
+            for (uint32_t i = threadIdx.x; i < cc; i += TPB) {
+                out_idx[kept + i] = sc_idx[i];
+                out_apx[kept + i] = sc_apx[i];
+            }
+            kept += cc;
+            __syncthreads();
+        }
+        const uint32_t used = min(prov, CH);
+        for (uint32_t i = threadIdx.x; i < used; i += TPB) {
+            itile[i] = 0;
+            itile[CH + i] = 0;
+        }
+        if (threadIdx.x == 0) s_count = kept;
+        __syncthreads();
+    };
     PH(0);  // preamble: collect, clears
     int tile_no = 0;
     for (int32_t t0 = 0; t0 < U; t0 += TCOLS, ++tile_no) {
@@ -395,8 +452,11 @@ __global__ void __launch_bounds__(TPB) k_tail_select(const ST* __restrict__ S, i
                     __syncthreads();
                 }
                 setup(tile_no);
+                PH(2);  // ranges + prefix scan + piece table
                 drain(false);
+                PH(4);  // piece descriptors, loads, LDS atomics (this wave)
                 __syncthreads();
+                PH(5);  // wait for the other waves
             }
         }
         if (pipelined && t0 + TCOLS < U) {  // next tile's ranges, pieces and first loads: they fly during the select work
@@ -530,60 +590,28 @@ __global__ void __launch_bounds__(TPB) k_tail_select(const ST* __restrict__ S, i
                     }
                 }
             }
-            if (tile_no == 1) {  // one refresh after 2 tiles: costs three barriers, tightens the rest
-                __syncthreads();
-                block_threshold(hist, wtot, &s_thr, kk, eps);
-            }
         }
         PH(tile_no == 0 ? 7 : 8);  // histogram + emit
         __syncthreads();
         PH(9);
+        // Threshold refresh: once after the second tile (costs three barriers, tightens the rest), and whenever the
+        // provisional list has grown large (wide error bands, e.g. bf16 operands): then it is compacted as well, so
+        // that it only overflows — and the row falls back to the exact path — when the band itself is that crowded.
+        {
+            const uint32_t prov = s_count;  // (block-uniform after the barrier)
+            const bool crowded = prov > (uint32_t)cap / 4 && prov <= (uint32_t)cap;
+            if (tile_no == 1 || crowded) block_threshold(hist, wtot, &s_thr, kk, eps);
+            if (crowded) compact(s_thr);
+        }
     }
 
     // ---- compaction of the provisional list by the final threshold (in place) ------------------------
-    const uint32_t prov = s_count;
-    if (prov > (uint32_t)cap) {  // provisional overflow: the exact fallback redoes this row
-        if (threadIdx.x == 0) cand_cnt[r] = (int32_t)min(prov, (uint32_t)0x7fffffff);
+    if (s_count > (uint32_t)cap) {  // provisional overflow: the exact fallback redoes this row
+        if (threadIdx.x == 0) cand_cnt[r] = (int32_t)min(s_count, (uint32_t)0x7fffffff);
         return;
     }
     block_threshold(hist, wtot, &s_thr, kk, eps);  // final: the whole row is in the histogram
-    const float thr = s_thr;
-    int32_t kv[MAX_PER_THREAD];
-    float kx[MAX_PER_THREAD];
-#pragma unroll
-    for (int j = 0; j < MAX_PER_THREAD; ++j) {
-        const uint32_t i = threadIdx.x + (uint32_t)j * TPB;
-        kv[j] = -1;
-        kx[j] = 0.f;
-        if (i < prov) {
-            kv[j] = out_idx[i];
-            kx[j] = out_apx[i];
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) s_count = 0;
-    __syncthreads();
-    {
-        uint32_t m = 0;
-#pragma unroll
-        for (int j = 0; j < MAX_PER_THREAD; ++j)
-            if (kv[j] >= 0 && kx[j] >= thr) m |= 1u << j;
-        const uint32_t cnt = __popc(m);
-        const uint32_t incl = wave_incl_scan(cnt);
-        const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-        uint32_t base = 0;
-        if (lane == 63 && total > 0) base = atomicAdd(&s_count, total);
-        base = __builtin_amdgcn_readlane(base, 63);
-        const uint32_t first = base + incl - cnt;
-#pragma unroll
-        for (int j = 0; j < MAX_PER_THREAD; ++j) {
-            if (m & (1u << j)) {
-                const uint32_t pos = first + __popc(m & ((1u << j) - 1u));
-                out_idx[pos] = kv[j];
-                out_apx[pos] = kx[j];
-            }
-        }
-    }
+    compact(s_thr);
     __syncthreads();
     if (threadIdx.x == 0) cand_cnt[r] = (int32_t)s_count;
     PH(10);  // final compaction
@@ -624,7 +652,6 @@ void launch_tail_select(const Train& tr, const int32_t* d_colmap, bool has_tail,
                         int32_t n_rows, const int32_t* d_row_user, int32_t k, float eps, int32_t cap,
                         int32_t* cand_idx, float* cand_approx, int32_t* cand_cnt, float* cand_eps, hipStream_t st) {
     if (n_rows <= 0) return;
-    KN_REQUIRE(cap <= TPB * MAX_PER_THREAD, KNNCF_E_INVALID, "select: shortlist store larger than the compaction window");
     const int32_t U = tr.U;
     int32_t kk = k < U - 1 ? k : U - 1;
     if (kk < 1) kk = 1;
