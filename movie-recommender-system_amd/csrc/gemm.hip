@@ -69,8 +69,8 @@ void launch_colmap(const Train& tr, int32_t H, int32_t* d_colmap, hipStream_t st
 
 // ---- GEMM --------------------------------------------------------------------------------
 // Tile configurations (BK = 64 for both; a wave always owns a WM*32 x 64 sub-tile):
-//   small: 128 x 128, 4 waves (2 x 2), WM = 2, 64 KiB LDS, 2 workgroups per CU
-//   large: 256 x 256, 8 waves (2 x 4), WM = 4, 128 KiB LDS, 1 workgroup per CU — half the L2 -> LDS operand
+//   small: 128 x 128, 4 waves (2 x 2), WM = WN = 2, 64 KiB LDS, 2 workgroups per CU
+//   large: 256 x 256, 8 waves (2 x 4), WM = 4, WN = 2, 132 KiB LDS, 1 workgroup per CU — half the L2 -> LDS operand
 //          traffic per flop (at the MFMA peak the 128 x 128 tile asks the L2 for ~39 TB/s, more than it has)
 static constexpr int BK = 64;
 
@@ -106,12 +106,12 @@ __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-template <bool F16, class OT, int WM, int WAVES_M, int WAVES_N>
+template <bool F16, class OT, int WM, int WN, int WAVES_M, int WAVES_N>
 __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64)
 k_gemm_nt_bf16(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, OT* __restrict__ C, int tiles_m,
                int tiles_n, int k_tiles, int64_t lda, int64_t ldb, int64_t ldc) {
     constexpr int WAVES = WAVES_M * WAVES_N;
-    constexpr int TBM = WAVES_M * WM * 32, TBN = WAVES_N * 64;
+    constexpr int TBM = WAVES_M * WM * 32, TBN = WAVES_N * WN * 32;
     static_assert(TBM == TBN, "square block tiles: both operand tiles share one staging routine");
     constexpr int TILE_BYTES = TileGeom<TBM>::TILE_BYTES, STAGE_BYTES = TileGeom<TBM>::STAGE_BYTES;
     constexpr int LOADS_PER_STAGE = 2 * (TBM / 8 / WAVES);  // LDS-DMA instructions per wave per stage
@@ -140,11 +140,11 @@ k_gemm_nt_bf16(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, OT* _
     const bf16_t* Ag = A + (int64_t)tm * TBM * lda;
     const bf16_t* Bg = B + (int64_t)tn * TBN * ldb;
 
-    f32x16 acc[WM][2];
+    f32x16 acc[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -161,8 +161,9 @@ k_gemm_nt_bf16(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, OT* _
             stage_tile<TBM, WAVES>(Ag + (int64_t)(kt + 1) * BK, lda, nxt, wave, lane);
             stage_tile<TBN, WAVES>(Bg + (int64_t)(kt + 1) * BK, ldb, nxt + TILE_BYTES, wave, lane);
             // tile kt landed; tile kt+1 (LOADS_PER_STAGE DMAs of this wave) stays in flight across the barrier
-            static_assert(LOADS_PER_STAGE == 8, "the counted vmcnt below assumes 8 LDS-DMA instructions per wave per stage");
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            static_assert(LOADS_PER_STAGE == 8 || LOADS_PER_STAGE == 16, "the counted vmcnt below assumes 8 or 16 LDS-DMA instructions per wave per stage");
+            if (LOADS_PER_STAGE == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -173,47 +174,82 @@ k_gemm_nt_bf16(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, OT* _
             bf16x8 a[WM];
 #pragma unroll
             for (int i = 0; i < WM; ++i) a[i] = read_frag(cur, wr * (WM * 32) + i * 32 + frow, ks * 2 + fhalf);
-            const bf16x8 b0 = read_frag(cur + TILE_BYTES, wc * 64 + frow, ks * 2 + fhalf);
-            const bf16x8 b1 = read_frag(cur + TILE_BYTES, wc * 64 + 32 + frow, ks * 2 + fhalf);
+            bf16x8 b[WN];
 #pragma unroll
-            for (int i = 0; i < WM; ++i) {
-                acc[i][0] = mfma<F16>(a[i], b0, acc[i][0]);
-                acc[i][1] = mfma<F16>(a[i], b1, acc[i][1]);
-            }
+            for (int j = 0; j < WN; ++j) b[j] = read_frag(cur + TILE_BYTES, wc * (WN * 32) + j * 32 + frow, ks * 2 + fhalf);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    // operands swapped (D' = B A^T): a lane then holds ONE row of S and groups of 4 consecutive columns
+                    acc[i][j] = mfma<F16>(b[j], a[i], acc[i][j]);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // everyone is done reading `cur` before it is restaged
         asm volatile("" ::: "memory");
     }
 
-    // C/D layout of v_mfma_f32_32x32x16: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    OT* Cg = C + ((int64_t)tm * TBM + wr * (WM * 32)) * ldc + (int64_t)tn * TBN + wc * 64;
+    // ---- epilogue: through LDS, so that C leaves in full 16-byte pieces of contiguous rows --------------------
+    // D layout of v_mfma_f32_32x32x16 with the operands swapped: lane (frow, fhalf) holds row frow of the 32 x 32 block,
+    // register e holds column (e & 3) + 8 (e >> 2) + 4 fhalf: four groups of 4 consecutive columns.  Each group is
+    // converted and written to an LDS image of the tile ([row][col], rows padded by 16 B); then every thread copies
+    // 16-byte pieces of rows to global memory (one wave instruction = 1 KiB of contiguous C).  Storing the
+    // accumulators directly costs one 2-byte store per element: 1024 wave-wide store instructions per 256 x 256 tile,
+    // as long as the tile's MFMA work.  fp32 C does not fit in one LDS image: one pass per wave row.
+    {
+        constexpr int ESZ = (int)sizeof(OT);
+        constexpr int RS = TBN * ESZ + 16;                              // LDS row stride
+        constexpr int PASSES = (ESZ == 2) ? 1 : WAVES_M;
+        constexpr int PASS_ROWS = TBM / PASSES;
+        constexpr int CH = TBN * ESZ / 16;                              // 16-byte pieces per row
+        for (int pass = 0; pass < PASSES; ++pass) {
+            if (PASSES == 1 || wr == pass) {
+                const int row0 = (PASSES == 1) ? wr * (WM * 32) : 0;
 #pragma unroll
-    for (int i = 0; i < WM; ++i)
+                for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < WN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
-                int col = j * 32 + frow;
-                Cg[(int64_t)row * ldc + col] = (OT)acc[i][j][e];
+                        for (int g = 0; g < 4; ++g) {
+                            char* dst = lds + (row0 + i * 32 + frow) * RS + (wc * (WN * 32) + j * 32 + 8 * g + 4 * fhalf) * ESZ;
+                            if (ESZ == 2) {
+                                typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+                                h4 v;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = (_Float16)acc[i][j][4 * g + e];
+                                *reinterpret_cast<h4*>(dst) = v;
+                            } else {
+                                *reinterpret_cast<float4*>(dst) = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                            }
+                        }
             }
+            __syncthreads();
+            OT* Cg = C + ((int64_t)tm * TBM + pass * PASS_ROWS) * ldc + (int64_t)tn * TBN;
+            for (int idx = threadIdx.x; idx < PASS_ROWS * CH; idx += WAVES * 64) {
+                const int row = idx / CH, ch = idx - row * CH;
+                const uint4 v = *reinterpret_cast<const uint4*>(lds + row * RS + ch * 16);
+                *reinterpret_cast<uint4*>(reinterpret_cast<char*>(Cg + (int64_t)row * ldc) + ch * 16) = v;
+            }
+            if (pass + 1 < PASSES) __syncthreads();
+        }
+    }
 }
 
-template <bool F16, class OT, int WM, int WAVES_M, int WAVES_N>
+template <bool F16, class OT, int WM, int WN, int WAVES_M, int WAVES_N>
 static void launch_gemm_cfg(const bf16_t* A, const bf16_t* B, OT* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                             int64_t ldb, int64_t ldc, hipStream_t st) {
     constexpr int TB = WAVES_M * WM * 32;
-    constexpr int SMEM = 2 * TileGeom<TB>::STAGE_BYTES;
+    constexpr int EPI = (TB / (sizeof(OT) == 2 ? 1 : WAVES_M)) * (TB * (int)sizeof(OT) + 16);  // epilogue image of the tile
+    constexpr int SMEM = 2 * TileGeom<TB>::STAGE_BYTES > EPI ? 2 * TileGeom<TB>::STAGE_BYTES : EPI;
     const int64_t tiles = (M / TB) * (N / TB);
     KN_REQUIRE(tiles > 0 && tiles < (1ll << 31), KNNCF_E_INVALID, "gemm: grid too large");
     static bool attr_set = false;
     if (!attr_set) {
-        KN_HIP(hipFuncSetAttribute((const void*)k_gemm_nt_bf16<F16, OT, WM, WAVES_M, WAVES_N>,
+        KN_HIP(hipFuncSetAttribute((const void*)k_gemm_nt_bf16<F16, OT, WM, WN, WAVES_M, WAVES_N>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         attr_set = true;
     }
-    k_gemm_nt_bf16<F16, OT, WM, WAVES_M, WAVES_N><<<(unsigned)tiles, WAVES_M * WAVES_N * 64, SMEM, st>>>(
+    k_gemm_nt_bf16<F16, OT, WM, WN, WAVES_M, WAVES_N><<<(unsigned)tiles, WAVES_M * WAVES_N * 64, SMEM, st>>>(
         A, B, C, (int)(M / TB), (int)(N / TB), (int)(K / BK), lda, ldb, ldc);
     KN_HIP(hipGetLastError());
 }
@@ -221,9 +257,11 @@ static void launch_gemm_cfg(const bf16_t* A, const bf16_t* B, OT* C, int64_t M, 
 template <bool F16, class OT>
 static void launch_gemm_t(const bf16_t* A, const bf16_t* B, OT* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                           int64_t ldb, int64_t ldc, hipStream_t st) {
+    // (a 4-wave variant of the large tile, each wave a 128 x 128 sub-tile in 256 accumulator registers — a third
+    // less LDS read traffic per flop — measured the same: 30.6 vs 30.7 ms at K = 448, 52.8 vs 51.9 ms at K = 1024)
     static const bool force_small = getenv("KNNCF_GEMM_TILE128") != nullptr;  // A/B switch for measurements
-    if (M % 256 == 0 && N % 256 == 0 && !force_small) launch_gemm_cfg<F16, OT, 4, 2, 4>(A, B, C, M, N, K, lda, ldb, ldc, st);
-    else launch_gemm_cfg<F16, OT, 2, 2, 2>(A, B, C, M, N, K, lda, ldb, ldc, st);
+    if (M % 256 == 0 && N % 256 == 0 && !force_small) launch_gemm_cfg<F16, OT, 4, 2, 2, 4>(A, B, C, M, N, K, lda, ldb, ldc, st);
+    else launch_gemm_cfg<F16, OT, 2, 2, 2, 2>(A, B, C, M, N, K, lda, ldb, ldc, st);
 }
 
 // C is fp16 (c_fp16) or fp32; operands fp16 (fp16) or bf16.  M, N multiples of 128 (256 selects the large tile)
