@@ -130,6 +130,13 @@ int knncf_neighbors(knncf_handle* h, int32_t u, int32_t cap, int32_t* ids, doubl
                     int32_t* count);
 int knncf_predict(knncf_handle* h, int predictor, int32_t user, int32_t item, double* out);
 
+/* recommendations(train, predictor)(user, n) shared/predictions.scala:651-674 (called by
+ * recommend/Recommender.scala:85-88 with n = 3): every train item `user` has not rated, predicted with `predictor`,
+ * ordered by (prediction descending, raw item id ascending); the first min(n, #unrated) are written, *count of them.
+ * An unknown user has rated nothing (every prediction is the global average: pure id order). */
+int knncf_recommend(knncf_handle* h, int predictor, int32_t user, int32_t n, int32_t* items,
+                    double* predictions, int32_t* count);
+
 /* ---- batch ---------------------------------------------------------------- */
 int knncf_predict_batch(knncf_handle* h, int predictor, const int32_t* users,
                         const int32_t* items, int64_t n, double* out);

@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "obj")
 LIB = os.path.join(HERE, "libknncf.so")
 CLI = os.path.join(HERE, "knncf")
-SOURCES = ["api.cpp", "prep.hip", "sort_util.hip", "gemm.hip", "select.hip", "rerank.hip", "predict.hip", "neighbours.hip"]
+SOURCES = ["api.cpp", "prep.hip", "sort_util.hip", "gemm.hip", "select.hip", "rerank.hip", "predict.hip", "neighbours.hip", "reco.hip"]
 HEADERS = ["common.h", "engine.h", os.path.join("..", "..", "include", "knncf.h")]
 # -ffp-contract=off: the fp64 kernels must round exactly like the reference's JVM arithmetic (no FMA)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",

@@ -55,6 +55,9 @@ struct knncf_handle {
     int32_t* pinned_cnt = nullptr;
     size_t pinned_cap = 0;
     SelectScratch sel;
+    DArr<int32_t> reco_users, reco_items, reco_out_items;
+    DArr<double> reco_pred, reco_out_preds;
+    DArr<uint8_t> reco_rated;
     DArr<int32_t> build_list, build_count;
     DArr<uint32_t> first_row;
     // test scratch
@@ -503,6 +506,42 @@ void do_fit_device(knncf_handle* h, const int32_t* d_users, const int32_t* d_ite
     }
 }
 
+// recommendations(ratings, predictor)(user, n) shared/predictions.scala:651-674
+void do_recommend(knncf_handle* h, int predictor, int32_t user, int32_t n, int32_t* out_items, double* out_preds, int32_t* count) {
+    require_fitted(h);
+    KN_REQUIRE(count && n >= 0 && (n == 0 || (out_items && out_preds)), KNNCF_E_INVALID, "bad arguments");
+    *count = 0;
+    Train& tr = h->tr;
+    if (n == 0 || tr.I == 0) return;
+    hipStream_t st = h->stream;
+    const int32_t du = dense_user(h, user);
+    KN_REQUIRE(du < 0 ? h->cfg.shard_rank == 0 : (du >= tr.own_lo && du < tr.own_hi), KNNCF_E_STATE,
+               "recommend: the user belongs to another shard");
+    const int32_t I = tr.I;
+    h->reco_users.ensure(I); h->reco_items.ensure(I); h->reco_pred.ensure(I); h->reco_rated.ensure(I);
+    launch_reco_rows(tr, user, du, h->reco_users.p, h->reco_items.p, h->reco_rated.p, st);
+    // one prediction batch over every train item (the rated ones are dropped by the ordering below)
+    run_predict(h, predictor, h->reco_users.p, h->reco_items.p, nullptr, I, nullptr, nullptr, h->reco_pred.p);
+    PrepScratch& sc = h->prep;
+    sc.k64_a.ensure(I); sc.k64_b.ensure(I); sc.v32_a.ensure(I); sc.v32_b.ensure(I);
+    launch_reco_order(tr, sc.sort, h->reco_pred.p, h->reco_rated.p, sc.k64_a.p, sc.k64_b.p, sc.v32_a.p, sc.v32_b.p, st);
+    int64_t n_rated = 0;
+    if (du >= 0) {
+        int64_t two[2];
+        KN_HIP(hipMemcpyAsync(two, tr.u_ptr.p + du, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        KN_HIP(hipStreamSynchronize(st));
+        n_rated = two[1] - two[0];
+    }
+    const int32_t m = (int32_t)std::min<int64_t>(n, (int64_t)I - n_rated);
+    if (m <= 0) return;
+    h->reco_out_items.ensure(m); h->reco_out_preds.ensure(m);
+    launch_reco_take(tr, m, sc.v32_b.p, h->reco_pred.p, h->reco_out_items.p, h->reco_out_preds.p, st);
+    KN_HIP(hipMemcpyAsync(out_items, h->reco_out_items.p, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    KN_HIP(hipMemcpyAsync(out_preds, h->reco_out_preds.p, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, st));
+    KN_HIP(hipStreamSynchronize(st));
+    *count = m;
+}
+
 }  // namespace
 
 extern "C" {
@@ -752,6 +791,10 @@ int knncf_predict_batch(knncf_handle* h, int predictor, const int32_t* users, co
 
 int knncf_predict(knncf_handle* h, int predictor, int32_t user, int32_t item, double* out) {
     return knncf_predict_batch(h, predictor, &user, &item, 1, out);
+}
+
+int knncf_recommend(knncf_handle* h, int predictor, int32_t user, int32_t n, int32_t* items, double* predictions, int32_t* count) {
+    return guarded(h, [&] { do_recommend(h, predictor, user, n, items, predictions, count); });
 }
 
 int knncf_mae_device(knncf_handle* h, int predictor, const int32_t* d_users, const int32_t* d_items,

@@ -234,8 +234,9 @@ double timed_ms(const std::function<void()>& f) {
 }
 
 struct Args {
-    std::string cmd, train, test, separator = "\t", json, master;
+    std::string cmd, train, test, separator = "\t", json, master, data, personal;
     int num_measurements = 0, k = 300, device = 0;
+    bool any_size = false;
 };
 
 Json meta(const Args& a, bool with_master) {
@@ -361,10 +362,76 @@ Json run_distributed(const Args& a, const Ratings& train, const Ratings& test) {
     return out;
 }
 
+// recommend/Recommender.scala:40-54: personal.csv is split on "," and trimmed; the header row (column 0 == "id") and
+// rows without a third column become rating 0 and are filtered out; the rest are ratings of user 944.  Column 1 is
+// the movie name (for every row, rated or not).  A non-numeric id or rating throws in the reference: fail loudly.
+bool load_personal(const std::string& path, Ratings* out, std::vector<std::pair<int32_t, std::string>>* names, std::string* err) {
+    std::ifstream f(path);
+    if (!f) { *err = "cannot open " + path; return false; }
+    std::string line;
+    int64_t lineno = 0;
+    while (std::getline(f, line)) {
+        ++lineno;
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        std::vector<std::string> cols;
+        size_t pos = 0;
+        while (true) {
+            size_t q = line.find(',', pos);
+            if (q == std::string::npos) { cols.push_back(trim(line.substr(pos))); break; }
+            cols.push_back(trim(line.substr(pos, q - pos)));
+            pos = q + 1;
+        }
+        while (cols.size() > 1 && cols.back().empty()) cols.pop_back();  // String.split drops trailing empties
+        if (cols[0] == "id") { names->push_back({0, "header"}); continue; }
+        int32_t id;
+        if (!parse_int(cols[0], &id) || cols.size() < 2) { *err = path + ":" + std::to_string(lineno) + ": malformed personal row"; return false; }
+        names->push_back({id, cols[1]});
+        if (cols.size() < 3) continue;  // Rating(944, id, 0.0): filtered
+        char* endp = nullptr;
+        const double r = strtod(cols[2].c_str(), &endp);
+        if (cols[2].empty() || *endp != '\0') { *err = path + ":" + std::to_string(lineno) + ": malformed personal rating"; return false; }
+        if (r != 0) {
+            out->users.push_back(944);
+            out->items.push_back(id);
+            out->ratings.push_back(r);
+        }
+    }
+    return true;
+}
+
+Json run_recommend(const Args& a, const Ratings& data, const Ratings& personal,
+                   const std::vector<std::pair<int32_t, std::string>>& names) {  // recommend/Recommender.scala:68-89
+    Ratings aug = data;  // data.union(personal): file order, personal rows last
+    aug.users.insert(aug.users.end(), personal.users.begin(), personal.users.end());
+    aug.items.insert(aug.items.end(), personal.items.begin(), personal.items.end());
+    aug.ratings.insert(aug.ratings.end(), personal.ratings.begin(), personal.ratings.end());
+    Engine e(a.device, 300, KNNCF_SIM_COSINE);
+    e.fit(aug);
+    Json out = Json::Obj();
+    out.set("Meta", Json::Obj().set("data", Json::Str(a.data)).set("personal", Json::Str(a.personal)));
+    out.set("R.1", Json::Obj().set("PredUser1Item1", Json::Num(e.predict(KNNCF_PRED_KNN, 1, 1))));
+    check(e.h, knncf_reset_neighbors(e.h), "reset");  // R.2 builds fresh closures (:85-88)
+    int32_t ids[3], cnt = 0;
+    double preds[3];
+    check(e.h, knncf_recommend(e.h, KNNCF_PRED_KNN, 944, 3, ids, preds, &cnt), "recommend");
+    Json r2 = Json::Arr();
+    for (int32_t j = 0; j < cnt; ++j) {
+        std::string name;
+        bool found = false;
+        for (const auto& kv : names)  // .toMap: the last row with this id wins
+            if (kv.first == ids[j]) { name = kv.second; found = true; }
+        if (!found) throw Fail{"recommend: no movie name for item " + std::to_string(ids[j]) + " (movieNames(x._1) throws)"};
+        r2.push(Json::Arr().push(Json::Num(ids[j])).push(Json::Str(name)).push(Json::Num(preds[j])));
+    }
+    out.set("R.2", r2);
+    return out;
+}
+
 int usage() {
     fprintf(stderr,
             "usage: knncf {baseline|personalized|knn|distributed-baseline|load-check} --train FILE --test FILE\n"
-            "             [--separator SEP] [--num_measurements N] [--json FILE] [--master M] [--k K] [--device D]\n");
+            "             [--separator SEP] [--num_measurements N] [--json FILE] [--master M] [--k K] [--device D]\n"
+            "       knncf recommend --data FILE --personal FILE [--separator SEP] [--json FILE] [--any-size]\n");
     return 2;
 }
 
@@ -388,9 +455,42 @@ int main(int argc, char** argv) {
         else if (k == "--master") a.master = need("--master");
         else if (k == "--k") a.k = atoi(need("--k").c_str());
         else if (k == "--device") a.device = atoi(need("--device").c_str());
+        else if (k == "--data") a.data = need("--data");
+        else if (k == "--personal") a.personal = need("--personal");
+        else if (k == "--any-size") a.any_size = true;
         else { fprintf(stderr, "[knncf] unknown option %s\n", k.c_str()); return usage(); }
     }
     if (a.separator == "\\t") a.separator = "\t";
+    if (a.cmd == "recommend") {
+        if (a.data.empty() || a.personal.empty()) { fprintf(stderr, "[knncf] --data and --personal are required\n"); return usage(); }
+        Ratings data, personal;
+        std::vector<std::pair<int32_t, std::string>> names;
+        std::string err;
+        printf("\n******************************************************\n");
+        printf("Loading data from: %s\n", a.data.c_str());
+        if (!load_ratings(a.data, a.separator, &data, &err)) { fprintf(stderr, "[knncf] %s\n", err.c_str()); return 1; }
+        if (data.size() != 100000 && !a.any_size) {  // assert(data.length == 100000, "Invalid data") :36
+            fprintf(stderr, "[knncf] assertion failed: Invalid data (%lld rows; --any-size lifts the reference's check)\n", (long long)data.size());
+            return 1;
+        }
+        printf("Loading personal data from: %s\n", a.personal.c_str());
+        if (!load_personal(a.personal, &personal, &names, &err)) { fprintf(stderr, "[knncf] %s\n", err.c_str()); return 1; }
+        try {
+            std::ostringstream o;
+            write_json(run_recommend(a, data, personal, names), 0, o);
+            printf("%s\n", o.str().c_str());
+            if (!a.json.empty()) {
+                printf("Saving answers in: %s\n", a.json.c_str());
+                std::ofstream f(a.json);
+                f << o.str();
+            }
+        } catch (const Fail& f) {
+            fprintf(stderr, "[knncf] %s\n", f.msg.c_str());
+            return 1;
+        }
+        printf("\n");
+        return 0;
+    }
     if (a.train.empty() || (a.test.empty() && a.cmd != "load-check")) { fprintf(stderr, "[knncf] --train and --test are required\n"); return usage(); }
     Ratings train, test;
     std::string err;

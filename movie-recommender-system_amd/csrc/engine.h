@@ -157,4 +157,12 @@ void launch_user_keys(int64_t n, const int32_t* d_du, uint64_t* d_key, uint32_t*
 void launch_reduce_err(const double* d_abs_err, const uint8_t* d_owned, int64_t n, double* d_partials,
                        int64_t* d_counts, int32_t n_blocks, hipStream_t st);
 
+// ---- reco.hip: recommendations :651-674 -------------------------------------------------------------------------
+// rows (user, every train item) for the prediction batch + the mask of the items the user rated
+void launch_reco_rows(const Train& tr, int32_t user_raw, int32_t du, int32_t* d_users, int32_t* d_items, uint8_t* d_rated, hipStream_t st);
+// v_b = dense items ordered by (prediction descending, raw id ascending), rated items last
+void launch_reco_order(const Train& tr, SortWorkspace& ws, const double* d_pred, const uint8_t* d_rated, uint64_t* k_a, uint64_t* k_b,
+                       uint32_t* v_a, uint32_t* v_b, hipStream_t st);
+void launch_reco_take(const Train& tr, int32_t m, const uint32_t* d_order, const double* d_pred, int32_t* d_items, double* d_preds, hipStream_t st);
+
 }  // namespace knncf

@@ -56,7 +56,7 @@ EXPORTS = [
     "knncf_version", "knncf_status_string", "knncf_create", "knncf_destroy", "knncf_last_error",
     "knncf_fit", "knncf_fit_device", "knncf_num_users", "knncf_num_items", "knncf_global_avg",
     "knncf_user_avg", "knncf_item_avg", "knncf_item_avg_dev", "knncf_item_avg_dev_rdd", "knncf_similarity",
-    "knncf_knn_similarity", "knncf_neighbors", "knncf_predict", "knncf_predict_batch",
+    "knncf_knn_similarity", "knncf_neighbors", "knncf_predict", "knncf_recommend", "knncf_predict_batch",
     "knncf_predict_batch_device", "knncf_mae", "knncf_mae_device", "knncf_shard_view_get",
     "knncf_shard_commit", "knncf_get_timings", "knncf_reset_timings", "knncf_reset_neighbors",
     "knncf_set_k",
@@ -121,6 +121,7 @@ def load_library():
         getattr(L, n).argtypes = [C.c_void_p, C.c_int32, C.c_int32, _f64p]
     L.knncf_neighbors.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _i32p, _f64p, _i32p]
     L.knncf_predict.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_int32, _f64p]
+    L.knncf_recommend.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_int32, _i32p, _f64p, C.POINTER(C.c_int32)]
     L.knncf_predict_batch.argtypes = [C.c_void_p, C.c_int, _i32p, _i32p, C.c_int64, _f64p]
     L.knncf_predict_batch_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     L.knncf_mae.argtypes = [C.c_void_p, C.c_int, _i32p, _i32p, _f64p, C.c_int64, _f64p]
@@ -251,6 +252,15 @@ class Engine:
 
     def predict(self, predictor, u, i):
         return self._scalar(self._lib.knncf_predict, predictor, u, i)
+
+    def recommend(self, predictor, user, n):
+        """recommendations(train, predictor)(user, n) shared/predictions.scala:651-674: (item ids, predictions)"""
+        ids = np.empty(max(1, n), dtype=np.int32)
+        preds = np.empty(max(1, n), dtype=np.float64)
+        c = C.c_int32()
+        self._check(self._lib.knncf_recommend(self._h, predictor, user, n, ids.ctypes.data_as(_i32p),
+                                              preds.ctypes.data_as(_f64p), C.byref(c)))
+        return ids[:c.value].copy(), preds[:c.value].copy()
 
     # ---- batch -------------------------------------------------------------------------
     def predict_batch(self, predictor, users, items):

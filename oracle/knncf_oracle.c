@@ -859,3 +859,51 @@ double orc_pipeline_mae(orc_pipeline* p, const int32_t* users, const int32_t* it
     }
     return s / (double)n;
 }
+
+/* ---- recommendations :651-674 --------------------------------------------- */
+typedef struct { int32_t item; double pred; } reco_t;
+
+/* the reference's `order`: x before y iff (x._2 == y._2) ? x._1 < y._1 : x._2 > y._2.  Item ids are distinct,
+ * so this is a strict total order and the stable sortWith has exactly one outcome. */
+static int cmp_reco(const void* a, const void* b) {
+    const reco_t* x = (const reco_t*)a;
+    const reco_t* y = (const reco_t*)b;
+    if (x->pred == y->pred) return x->item < y->item ? -1 : (x->item > y->item ? 1 : 0);
+    return x->pred > y->pred ? -1 : 1;
+}
+
+int32_t orc_recommend(const orc_model* m, orc_pipeline* p, int simple_kind, int32_t user, int32_t n,
+                      int32_t* out_items, double* out_preds) {
+    if (n <= 0) return 0;
+    /* notRated = ratings.map(_.item).toSet.diff(items of `user`) :667 */
+    char* rated = (char*)calloc((size_t)m->I > 0 ? (size_t)m->I : 1, 1);
+    reco_t* r = (reco_t*)malloc(sizeof(reco_t) * (size_t)(m->I > 0 ? m->I : 1));
+    if (!rated || !r) { free(rated); free(r); return -1; }
+    int32_t du = lookup(m->uid, m->U, user);
+    if (du >= 0)
+        for (int64_t q = m->u_ptr[du]; q < m->u_ptr[du + 1]; ++q) rated[m->di[m->u_rows[q]]] = 1;
+    int32_t cnt = 0;
+    for (int32_t i = 0; i < m->I; ++i) {
+        if (rated[i]) continue;
+        const int32_t item = m->iid[i];
+        double pr;
+        if (p) pr = orc_pipeline_predict(p, user, item);
+        else {
+            switch (simple_kind) {
+                case 0: pr = orc_predict_global(m, user, item); break;
+                case 1: pr = orc_predict_user_avg(m, user, item); break;
+                case 2: pr = orc_predict_item_avg(m, user, item); break;
+                case 4: pr = orc_predict_baseline_spark(m, user, item); break;
+                default: pr = orc_predict_baseline(m, user, item); break;
+            }
+        }
+        r[cnt].item = item;
+        r[cnt].pred = pr;
+        ++cnt;
+    }
+    qsort(r, (size_t)cnt, sizeof(reco_t), cmp_reco);
+    if (cnt > n) cnt = n;
+    for (int32_t j = 0; j < cnt; ++j) { out_items[j] = r[j].item; out_preds[j] = r[j].pred; }
+    free(rated); free(r);
+    return cnt;
+}

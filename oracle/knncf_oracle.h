@@ -117,6 +117,14 @@ double orc_pipeline_predict(orc_pipeline*, int32_t u, int32_t i); /* :568-585 */
 double orc_pipeline_mae(orc_pipeline*, const int32_t* users, const int32_t* items,
                         const double* ratings, int64_t n, double* per_pred);
 
+/* recommendations(ratings, predictor)(user, n) shared/predictions.scala:651-674:
+ * every train item the user has not rated, predicted, ordered by (prediction
+ * descending, item id ascending), first n.  `p` non-NULL: the kNN / personalised
+ * predictor of the pipeline; p == NULL: the closed-form predictor `simple_kind`
+ * (0 global, 1 user, 2 item, 3 baseline, 4 baseline_spark) of the model.  Returns the number of entries written (<= n). */
+int32_t orc_recommend(const orc_model*, orc_pipeline* p, int simple_kind, int32_t user, int32_t n,
+                      int32_t* out_items, double* out_preds);
+
 #ifdef __cplusplus
 }
 #endif

@@ -94,6 +94,8 @@ def lib():
     L.orc_pipeline_neighbors.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _i32p, _f64p]
     L.orc_pipeline_mae.restype = C.c_double
     L.orc_pipeline_mae.argtypes = [C.c_void_p, _i32p, _i32p, _f64p, C.c_int64, _f64p]
+    L.orc_recommend.restype = C.c_int32
+    L.orc_recommend.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int32, C.c_int32, _i32p, _f64p]
     _lib = L
     return L
 
@@ -215,6 +217,15 @@ class Model:
     def fresh_similarity(self, sim_kind, u, v):
         return lib().orc_fresh_similarity(self._h, sim_kind, u, v)
 
+    def recommend(self, kind, user, n):
+        """recommendations(ratings, <closed-form predictor kind>)(user, n) shared/predictions.scala:651-674"""
+        ids = np.empty(max(1, n), dtype=np.int32)
+        preds = np.empty(max(1, n), dtype=np.float64)
+        c = lib().orc_recommend(self._h, None, kind, user, n, _p(ids, _i32p), _p(preds, _f64p))
+        if c < 0:
+            raise OracleError(c)
+        return ids[:c].copy(), preds[:c].copy()
+
     def pipeline(self, sim_kind=SIM_COSINE, k=-1):
         return Pipeline(self, sim_kind, k)
 
@@ -251,6 +262,15 @@ class Pipeline:
 
     def predict(self, u, i):
         return lib().orc_pipeline_predict(self._h, u, i)
+
+    def recommend(self, user, n):
+        """recommendations(ratings, predictor(..., this pipeline))(user, n) shared/predictions.scala:651-674"""
+        ids = np.empty(max(1, n), dtype=np.int32)
+        preds = np.empty(max(1, n), dtype=np.float64)
+        c = lib().orc_recommend(self.model._h, self._h, 0, user, n, _p(ids, _i32p), _p(preds, _f64p))
+        if c < 0:
+            raise OracleError(c)
+        return ids[:c].copy(), preds[:c].copy()
 
     def mae(self, users, items, ratings, return_predictions=False):
         u, i, r = _i32(users), _i32(items), _f64(ratings)

@@ -278,3 +278,22 @@ def mae(predict, data):  # :69-86
     for (u, i, r) in data:
         acc, n = abs(r - predict(u, i)) + acc, n + 1
     return acc / n
+
+
+def recommendations(ratings, predict):  # :651-674
+    import functools
+
+    def order(x, y):  # sortWith(order): x before y
+        return x[0] < y[0] if x[1] == y[1] else x[1] > y[1]
+
+    cache = {}
+
+    def reco(user, n):
+        if (user, n) not in cache or not cache[(user, n)]:
+            not_rated = scala_order(set(i for (_, i, _) in ratings) - set(i for (u, i, _) in ratings if u == user))
+            cand = [(x, predict(user, x)) for x in not_rated]  # notRated.toSeq.map: HashSet iteration order
+            cand.sort(key=functools.cmp_to_key(lambda x, y: -1 if order(x, y) else (1 if order(y, x) else 0)))  # stable
+            cache[(user, n)] = cand[:n]
+        return cache[(user, n)]
+
+    return reco

@@ -93,3 +93,60 @@ def test_entry_points_against_oracle(cli, tmp_path, oracle, syn100k):
     assert dz["D.1"]["4.Item1AvgDev"] == m.items_avg_dev_spark(1)
     assert dz["D.1"]["5.PredUser1Item1"] == m.predict(oracle.KIND_BASELINE_SPARK, 1, 1)
     assert dz["D.1"]["6.Mae"] == pytest.approx(m.mae(oracle.KIND_BASELINE_SPARK, *T), abs=1e-12)
+
+
+def test_recommender_size_assert_and_personal_quirks(cli, tmp_path):
+    """recommend/Recommender.scala:36: data must hold exactly 100000 rows (assert); :40-54: personal.csv quirks —
+    checked on the CPU up to the point where the GPU engine is created"""
+    data = tmp_path / "u.data"
+    data.write_text("1\t10\t4\t0\n2\t10\t5\t0\n")
+    pers = tmp_path / "personal.csv"
+    pers.write_text("id,title,rating\n10,Some Movie,5\n11,Unrated Movie,\n")
+    out = subprocess.run([cli, "recommend", "--data", str(data), "--personal", str(pers)], capture_output=True, text=True)
+    assert out.returncode == 1 and "Invalid data" in out.stderr
+    bad = tmp_path / "bad.csv"
+    bad.write_text("id,title,rating\nabc,Movie,5\n")  # cols(0).toInt throws in the reference
+    out = subprocess.run([cli, "recommend", "--data", str(data), "--personal", str(bad), "--any-size"], capture_output=True, text=True)
+    assert out.returncode == 1 and "malformed personal row" in out.stderr
+    out = subprocess.run([cli, "recommend", "--data", str(data)], capture_output=True, text=True)
+    assert out.returncode == 2
+
+
+@pytest.mark.gpu
+def test_recommender_entry_point_against_oracle(cli, tmp_path, oracle, syn100k):
+    """recommend.Recommender (recommend/Recommender.scala:68-89): data ∪ personal ratings of user 944, R.1 prediction
+    and R.2 top-3 [id, name, prediction] for user 944 with k = 300"""
+    d = syn100k
+    data = str(tmp_path / "u.data")
+    with open(data, "w") as f:
+        for part in (d.train, d.test):  # the whole data set, like ml-100k/u.data
+            for u, i, r in zip(part.users, part.items, part.ratings):
+                f.write(f"{u}\t{i}\t{r:g}\t881250949\n")
+    all_items = np.unique(np.concatenate([d.train.items, d.test.items]))
+    rng = np.random.default_rng(944)
+    rated = rng.choice(all_items, size=25, replace=False)
+    lines = ["id,title,rating"]
+    personal = []
+    for it in all_items:
+        if it in rated:
+            r = int(rng.integers(1, 6))
+            lines.append(f"{it}, Movie {it} ,{r}")
+            personal.append((944, int(it), float(r)))
+        else:
+            lines.append(f"{it},Movie {it},")
+    pers = str(tmp_path / "personal.csv")
+    open(pers, "w").write("\n".join(lines) + "\n")
+    js = str(tmp_path / "reco.json")
+    n_data = len(d.train.users) + len(d.test.users)
+    args = [cli, "recommend", "--data", data, "--personal", pers, "--json", js] + ([] if n_data == 100000 else ["--any-size"])
+    out = subprocess.run(args, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    got = json.load(open(js))
+    users = np.concatenate([d.train.users, d.test.users, np.array([p[0] for p in personal], dtype=np.int32)])
+    items = np.concatenate([d.train.items, d.test.items, np.array([p[1] for p in personal], dtype=np.int32)])
+    ratings = np.concatenate([d.train.ratings, d.test.ratings, np.array([p[2] for p in personal])])
+    m = oracle.Model(users, items, ratings)
+    assert got["Meta"] == {"data": data, "personal": pers}
+    assert got["R.1"]["PredUser1Item1"] == m.pipeline(oracle.SIM_COSINE, 300).predict(1, 1)
+    ids, preds = m.pipeline(oracle.SIM_COSINE, 300).recommend(944, 3)
+    assert got["R.2"] == [[int(i), f"Movie {i}", p] for i, p in zip(ids.tolist(), preds.tolist())]

@@ -122,6 +122,40 @@ def test_ml100k_shape_all_neighbours_and_predictions(kn, oracle, synth, shuffle)
         e.close()
 
 
+def test_recommendations_equal_oracle(kn, oracle, synth):
+    """recommendations :651-674: ids and predictions bit for bit, ml-100k shape, the Recommender's
+    n = 3 and a longer list; kNN k = 300 (recommend/Recommender.scala:85-88), the baseline, and the all-ties case"""
+    d = synth.syn_100k()
+    tr = (d.train.users, d.train.items, d.train.ratings)
+    m = oracle.Model(*tr)
+    e = _engine(kn, tr, k=300)
+    p = m.pipeline(oracle.SIM_COSINE, 300)
+    users = np.unique(d.train.users)
+    n_items = len(np.unique(d.train.items))
+    for u in [int(x) for x in users[::97]] + [987654]:
+        for n in (3, 25):
+            ids, preds = e.recommend(kn.PRED_KNN, u, n)
+            oi, op = p.recommend(u, n)
+            assert ids.tolist() == oi.tolist(), f"user {u} n {n}"
+            assert preds.tolist() == op.tolist()
+        ids, preds = e.recommend(kn.PRED_BASELINE, u, 10)
+        oi, op = m.recommend(oracle.KIND_BASELINE, u, 10)
+        assert (ids.tolist(), preds.tolist()) == (oi.tolist(), op.tolist())
+        ids, preds = e.recommend(kn.PRED_GLOBAL_AVG, u, 7)  # every prediction equal: the 7 smallest unrated ids
+        oi, op = m.recommend(oracle.KIND_GLOBAL, u, 7)
+        assert (ids.tolist(), preds.tolist()) == (oi.tolist(), op.tolist())
+        assert ids.tolist() == sorted(ids.tolist())
+    # n beyond the number of unrated items: everything unrated, still ordered
+    u = int(users[0])
+    rated = int((d.train.users == u).sum())
+    ids, preds = e.recommend(kn.PRED_KNN, u, 10 * n_items)
+    assert len(ids) == n_items - rated
+    oi, op = p.recommend(u, 10 * n_items)
+    assert (ids.tolist(), preds.tolist()) == (oi.tolist(), op.tolist())
+    assert not set(ids.tolist()) & set(d.train.items[d.train.users == u].tolist())
+    e.close()
+
+
 @pytest.mark.parametrize("bf16", [False, True])
 @pytest.mark.parametrize("head", [64, 320, 0xFFFFFFFF])
 def test_hybrid_head_tail_split_is_exact(kn, oracle, syn100k, head, bf16):

@@ -123,6 +123,38 @@ def test_oracle_equals_literal_model_bitwise(oracle, seed):
         assert m.pipeline(kind, -1).mae(tu, ti, tr) == want
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_recommendations_equal_literal_model(oracle, seed):
+    """recommendations :651-674: unrated items by (prediction desc, id asc), first n — kNN and closed-form predictors,
+    a known user, a user without ratings in train, n larger than the number of unrated items, ties"""
+    rng = np.random.default_rng(100 + seed)
+    rows = _random_case(rng, n_users=10 + seed, n_items=16, n_ratings=60 + 6 * seed, half=(seed % 2 == 0), tiny_rows=seed % 2)
+    if not _no_zero_scale(rows):
+        pytest.skip("scale() == 0 corner")
+    m = oracle.Model(*_cols(rows))
+    users = sorted(set(u for (u, _, _) in rows))
+    k = 3
+    cos = sm.adjusted_cosine_similarity_function(rows)
+    knn = sm.recommendations(rows, sm.predictor(rows, sm.weighted_sum_deviation(rows, sm.get_similarity(rows, k, cos))))
+    p = m.pipeline(oracle.SIM_COSINE, k)
+    for u in users[:4] + [424242]:
+        for n in (1, 3, 100):
+            want = knn(u, n)
+            ids, preds = p.recommend(u, n)
+            assert ids.tolist() == [x for x, _ in want]
+            assert preds.tolist() == [v for _, v in want]
+    base = sm.recommendations(rows, sm.compute_prediction(rows))
+    g = sm.average(rows)
+    glob = sm.recommendations(rows, lambda u, i: g)  # all predictions equal: pure id order
+    for u in users[:3] + [424242]:
+        for n in (2, 50):
+            ids, preds = m.recommend(oracle.KIND_BASELINE, u, n)
+            assert (ids.tolist(), preds.tolist()) == ([x for x, _ in base(u, n)], [v for _, v in base(u, n)])
+            ids, preds = m.recommend(oracle.KIND_GLOBAL, u, n)
+            assert (ids.tolist(), preds.tolist()) == ([x for x, _ in glob(u, n)], [v for _, v in glob(u, n)])
+            assert ids.tolist() == sorted(ids.tolist())
+
+
 def test_invariants_on_ml100k_shape(oracle, syn100k):
     tr, te = syn100k.train, syn100k.test
     m = oracle.Model(tr.users, tr.items, tr.ratings)
