@@ -163,26 +163,40 @@ def main():
         launches = max(1, tm["gemm_launches"])  # every per-row-block kernel is launched once per GEMM launch
         k = args.k
 
-        def roof(name, bound, ms, work, peak, unit, note, launches=launches):
+        # HBM traffic per launch from the committed PMC passes of this workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+        # separate runs, corrected as MI355X_MICROARCH.md prescribes: see profiles/README.md); null for any other setup —
+        # counters cannot be collected from inside this process
+        pmc = {}
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01g_pmc_traffic_syn25m_1gpu.json")
+        if world == 1 and split.name == "syn-25m" and args.engine_flags == 0 and args.head_items == 0 and args.k == 300 and os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                pmc = json.load(f)["kernels"]
+
+        def roof(name, bound, ms, work, peak, unit, note, launches=launches, key=None):
             """achieved = ALGORITHMIC work per launch / average launch duration (HIP events on the kernel's stream)"""
             s_per_launch = ms / launches / 1e3
             ach = (work / launches) / s_per_launch / 1e12 if s_per_launch > 0 else 0.0
-            return {"bound": bound, "kernel": name, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
-                    "launches_per_step": launches / steps, "avg_launch_ms": s_per_launch * 1e3, "traffic": None,
-                    "algorithmic_work": note}
+            r = {"bound": bound, "kernel": name, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+                 "launches_per_step": launches / steps, "avg_launch_ms": s_per_launch * 1e3, "traffic": None,
+                 "algorithmic_work": note, "algorithmic_per_launch": work / launches}
+            if key in pmc:
+                r["traffic"] = pmc[key]["traffic_bytes_per_launch"]
+                r["traffic_source"] = "profiles/r01g_pmc_traffic_syn25m_1gpu.json (2 x FETCH_SIZE + WRITE_SIZE, bytes per launch)"
+            return r
 
         kernels = {
             "k_gemm_nt_bf16": roof("k_gemm_nt_bf16 (user x user similarity, dense head, MFMA)", "mfma", tm["gemm_ms"],
                                    tm["gemm_flops_algorithmic"], MFMA_BF16_DENSE_PEAK_TFLOPS, "TFLOP/s",
-                                   "2 * rows * (U-1) * head_items flops per launch"),
+                                   "2 * rows * (U-1) * head_items flops per launch", key="k_gemm_nt_bf16"),
             "k_tail_select": roof("k_tail_select (sparse tail + histogram select)", "hbm", tm["select_ms"],
                                   tm["select_row_bytes"] + 4.0 * tm["tail_pair_updates"], HBM_PEAK_TBPS, "TB/s",
-                                  "panel entry size (2 B fp16 / 4 B fp32) * rows * U, read once + 4 B per tail pair product (packed column | Q0.16 value)"),
+                                  "panel entry size (2 B fp16 / 4 B fp32) * rows * U, read once + 4 B per tail pair product (packed column | Q0.16 value)",
+                                  key="k_tail_select"),
             "k_rerank": roof("k_rerank (exact fp64 re-rank + top-k)", "hbm", tm["rerank_ms"], tm["rerank_row_bytes"],
-                             HBM_PEAK_TBPS, "TB/s", "12 B * ratings of every shortlisted candidate"),
+                             HBM_PEAK_TBPS, "TB/s", "12 B * ratings of every shortlisted candidate", key="k_rerank"),
             "k_predict_knn": roof("k_predict_knn_items (weighted-sum prediction + MAE; the stage also holds the id lookup and the row sort)",
                                   "hbm", tm["predict_ms"], 12.0 * k * n_test * steps, HBM_PEAK_TBPS, "TB/s",
-                                  "12 * k B per prediction (SURVEY 8d)", launches=steps),
+                                  "12 * k B per prediction (SURVEY 8d)", launches=steps, key="k_predict_knn"),
         }
         kernels["k_gemm_nt_bf16"]["executed_tflops"] = (tm["gemm_flops_executed"] / launches) / (tm["gemm_ms"] / launches / 1e3) / 1e12 if tm["gemm_ms"] > 0 else 0.0
         stage_of = {"k_gemm_nt_bf16": "gemm_ms", "k_tail_select": "select_ms", "k_rerank": "rerank_ms", "k_predict_knn": "predict_ms"}
