@@ -10,6 +10,8 @@
 #include <algorithm>
 #include <vector>
 
+#include <stdlib.h>
+
 #include "engine.h"
 
 namespace knncf {
@@ -550,7 +552,8 @@ void prep_commit(Train& tr, PrepScratch& sc, hipStream_t st) {
         const double bytes = (double)I * (double)words * 12.0;
         size_t free_b = 0, total_b = 0;
         KN_HIP(hipMemGetInfo(&free_b, &total_b));
-        if (bytes < 0.15 * (double)(free_b + tr.item_bits.bytes() + tr.item_rank.bytes())) {
+        // (KNNCF_DEBUG_NO_ITEM_BITMAPS: test hook, forces the no-bitmap prediction path that huge shapes take)
+        if (bytes < 0.15 * (double)(free_b + tr.item_bits.bytes() + tr.item_rank.bytes()) && !getenv("KNNCF_DEBUG_NO_ITEM_BITMAPS")) {
             tr.ib_words = words;
             tr.item_bits.ensure((size_t)I * words);
             tr.item_rank.ensure((size_t)I * words);

@@ -224,6 +224,52 @@ def test_two_shards_on_one_gpu_equal_single_engine(kn, pkg, oracle, synth):
     assert total / count == pytest.approx(want, abs=MAE_TOL)
 
 
+def test_wide_shape_takes_the_large_u_paths(kn, oracle, synth):
+    """U = 300 000 users: the similarity row spans 19 column tiles (more than the per-entry counts held in
+    registers: select.hip reads the tile table per tile) and the item bitmaps no longer fit in LDS (prediction falls
+    back to k_predict_knn_rows: bitmaps in global memory, rows sorted by user).  Sampled users bit for bit."""
+    import torch
+
+    d = synth.syn_scaled(300_000, 4_000, 6_000_000, seed=77, half_stars=False)
+    dev = torch.device("cuda", 0)
+    tr = tuple(torch.from_numpy(a).to(dev) for a in (d.train.users, d.train.items, d.train.ratings))
+    te = tuple(torch.from_numpy(a).to(dev) for a in (d.test.users, d.test.items, d.test.ratings))
+    k = 50
+    e = kn.Engine(k=k, flags=kn.FLAG_VERIFY_BOUND)
+    e.fit_device(*tr)
+    preds = torch.zeros(len(d.test.users), dtype=torch.float64, device=dev)
+    s, c = e.mae_device(kn.PRED_KNN, *te, pred_out=preds)
+    preds = preds.cpu().numpy()
+    assert c == len(d.test.users) and np.isfinite(preds).all()
+    t = e.timings()
+    assert t["max_bound_violation"] <= 0.0
+    m = oracle.Model(d.train.users, d.train.items, d.train.ratings)
+    p = m.pipeline(oracle.SIM_COSINE, k)
+    users = np.unique(d.train.users)
+    for u in users[:: len(users) // 12][:12]:
+        ids, sims = e.neighbors(int(u))
+        oids, osims = p.neighbors(int(u))
+        assert ids.tolist() == oids.tolist(), f"user {u}"
+        assert sims.tolist() == osims.tolist()
+        rows = np.nonzero(d.test.users == u)[0]
+        for r_ in rows[:8]:
+            assert preds[r_] == p.predict(int(u), int(d.test.items[r_]))
+    e.close()
+
+
+def test_prediction_without_item_bitmaps(kn, oracle, synth, monkeypatch):
+    """shapes whose rater bitmaps would not fit in HBM predict through binary searches (k_predict_knn): forced here"""
+    monkeypatch.setenv("KNNCF_DEBUG_NO_ITEM_BITMAPS", "1")
+    d = synth.syn_100k()
+    tr = (d.train.users, d.train.items, d.train.ratings)
+    te = (d.test.users, d.test.items, d.test.ratings)
+    e = _engine(kn, tr, k=40)
+    want, preds = oracle.Model(*tr).pipeline(oracle.SIM_COSINE, 40).mae(*te, True)
+    np.testing.assert_array_equal(e.predict_batch(kn.PRED_KNN, te[0], te[1]), preds)
+    assert abs(e.mae(kn.PRED_KNN, *te) - want) <= MAE_TOL
+    e.close()
+
+
 def test_full_size_ml25m_shape_sampled_rows_and_invariants(kn, oracle, synth):
     """BASELINE's metric configuration (162 541 x 59 047, 20 M / 5 M ratings, k = 300): the oracle cannot
     finish all rows in seconds, so (i) a sample of users is checked bit for bit (neighbour ids, fp64
