@@ -193,12 +193,16 @@ void reset_neighbors(knncf_handle* h) {
 // per-pair error bound of the bf16 GEMM entry, excluding the per-row accumulation term that
 // select.hip adds from the row length: both operands rounded to bf16 (u = 2^-8, via fp32),
 // products exact in fp32, sum |x y| <= ||x|| ||y|| <= 1
-float gemm_eps_base(bool fp16) {
-    // bf16: 8 significant bits; fp16: 11 (|pre| <= 1; below 2^-14 the fp16 grid is absolute, 2^-25 per
-    // operand, folded into the constant: sum (|x| + |y|) 2^-25 <= 2 sqrt(n) 2^-25 < 6e-6 for n < 10^4)
-    const double u = ldexp(1.0, fp16 ? -11 : -8) * 1.001;
-    // + the tail's fp32 operand/product roundings (3 * 2^-24 of sum |x y| <= 1)
-    return (float)(2 * u + u * u + 4e-7 + (fp16 ? 6e-6 : 0.0));
+// split in two: the relative operand-rounding part (2u + u^2), which select.hip scales by the norm of the row's
+// head part (sum_head |x y| <= ||x_head|| ||y_head|| <= ||x_head||), and the absolute rest
+float gemm_eps_operand(bool fp16) {
+    const double u = ldexp(1.0, fp16 ? -11 : -8) * 1.001;  // bf16: 8 significant bits; fp16: 11
+    return (float)(2 * u + u * u);
+}
+float gemm_eps_rest(bool fp16) {
+    // the tail's fp32 operand/product roundings (3 * 2^-24 of sum |x y| <= 1); fp16: |pre| <= 1, below 2^-14 the
+    // grid is absolute, 2^-25 per operand: sum (|x| + |y|) 2^-25 <= 2 sqrt(n) 2^-25 < 6e-6 for n < 10^4
+    return (float)(4e-7 + (fp16 ? 6e-6 : 0.0));
 }
 
 // per-row shortlist storage: rows whose error band holds more candidates than this take the exact
@@ -311,8 +315,10 @@ void build_neighbors(knncf_handle* h, int32_t count) {
         KN_HIP(hipHostMalloc((void**)&h->pinned_cnt, (size_t)count * sizeof(int32_t), hipHostMallocDefault));
         h->pinned_cap = (size_t)count;
     }
-    // fp16 panel storage rounds the dense head once more (|S| <= 1 + eps: <= 2^-11 relative)
-    const float eps = gemm_eps_base(fp16) + (s_fp16 ? 4.9e-4f : 0.f);
+    // fp16 panel storage rounds the dense head once more: the GEMM clamps it to [-1, 1] first (the exact head sum lies
+    // there, so clamping only moves towards it), where half an fp16 ulp is at most 2^-12
+    const float eps_opnd = gemm_eps_operand(fp16);
+    const float eps_rest = gemm_eps_rest(fp16) + (s_fp16 ? 2.45e-4f : 0.f);
     hipStream_t sp = h->stream2;  // producer: densify, GEMM, sparse tail
     hipStream_t sc = h->stream;   // consumer: select, exact re-rank
     KN_HIP(hipEventRecord(h->ev_ready, sc));  // everything queued so far (fit, B panel) precedes the producer
@@ -342,7 +348,7 @@ void build_neighbors(knncf_handle* h, int32_t count) {
         {
             // sparse tail (LDS atomics per row tile) + histogram select, fused: one pass over S
             Stage s(h, &h->tm.select_ms, sc);
-            launch_tail_select(tr, h->colmap.p, head < tr.I, h->S[slot].p, s_fp16, U_pad, rows, d_rows, nt.k, eps, cap,
+            launch_tail_select(tr, h->colmap.p, head < tr.I, h->S[slot].p, s_fp16, U_pad, rows, d_rows, nt.k, eps_opnd, eps_rest, cap,
                                h->sel.cand_idx.p, h->sel.cand_approx.p, h->sel.cand_cnt.p, h->sel.cand_eps.p, sc);
             h->tm.tail_pair_updates += h->tail_pairs_full * ((double)rows / (double)tr.U);
             h->tm.select_row_bytes += (double)s_elem * (double)rows * (double)tr.U;

@@ -130,9 +130,9 @@ struct SelectScratch {
 };
 
 // per panel row: S[r][:] += sparse tail (items with colmap < 0), then threshold + shortlist:
-// candidates v with S[r][v] >= T_r - 2 eps
+// candidates v with S[r][v] >= T_r - 2 eps_r; eps_r = eps_opnd * ||head part of row r|| + eps_rest + per-row terms
 void launch_tail_select(const Train& tr, const int32_t* d_colmap, bool has_tail, const void* S, bool s_fp16, int64_t lds,
-                        int32_t n_rows, const int32_t* d_row_user, int32_t k, float eps, int32_t cap,
+                        int32_t n_rows, const int32_t* d_row_user, int32_t k, float eps_opnd, float eps_rest, int32_t cap,
                         int32_t* cand_idx, float* cand_approx, int32_t* cand_cnt, float* cand_eps, hipStream_t st);
 // exact fp64 similarities of the shortlists in reference order, stable top-k
 void launch_rerank(const Train& tr, NeighborTable& nt, int32_t n_rows, const int32_t* d_row_user,

@@ -216,7 +216,7 @@ k_gemm_nt_bf16(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, OT* _
                                 typedef __attribute__((ext_vector_type(4))) _Float16 h4;
                                 h4 v;
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] = (_Float16)acc[i][j][4 * g + e];
+                                for (int e = 0; e < 4; ++e) v[e] = (_Float16)fminf(fmaxf(acc[i][j][4 * g + e], -1.0f), 1.0f);  // (see api.cpp: eps_rest)
                                 *reinterpret_cast<h4*>(dst) = v;
                             } else {
                                 *reinterpret_cast<float4*>(dst) = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);

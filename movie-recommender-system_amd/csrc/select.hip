@@ -160,7 +160,7 @@ struct Raw8<_Float16> {
 template <class ST>
 __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ S, int64_t ld, int32_t n_rows,
                                                      const int32_t* __restrict__ row_user, TailArgs T, int32_t U,
-                                                     int32_t kk, float eps_base, int32_t cap, int32_t* __restrict__ cand_idx,
+                                                     int32_t kk, float eps_opnd, float eps_rest, int32_t cap, int32_t* __restrict__ cand_idx,
                                                      float* __restrict__ cand_approx, int32_t* __restrict__ cand_cnt,
                                                      float* __restrict__ cand_eps) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -216,23 +216,41 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
             }
         }
     };
-    // error of the Q0.16 rater-side factors: 2^-16 * sum over the row's tail entries of |pre(u, i)|, summed in a fixed
-    // order (position -> thread, then shuffles) so that the band is the same on every run
-    float tail_abs = 0.f;
+    // Two per-row quantities of the error band, summed in a fixed order (position -> thread, then shuffles) so that
+    // the band is the same on every run:
+    //  * tail_abs = sum over the row's tail entries of |pre(u, i)|: the Q0.16 rater-side factors err by 2^-16 each;
+    //  * head_sq  = sum over the row's HEAD entries of pre(u, i)^2: the operand roundings of the dense part err by
+    //    (2u + u^2) sum_head |x y| <= (2u + u^2) ||x_head|| ||y_head|| <= (2u + u^2) ||x_head||   (||y|| <= 1).
+    float tail_abs = 0.f, head_sq = 0.f;
     if (n_chunks > 0) {
-        for (int64_t p = ub + threadIdx.x; p < ue; p += TPB)
-            if (T.colmap[T.s_col[p]] < 0) tail_abs += fabsf((float)T.s_pre[p]);
+        for (int64_t p = ub + threadIdx.x; p < ue; p += TPB) {
+            const float x = (float)T.s_pre[p];
+            if (T.colmap[T.s_col[p]] < 0) tail_abs += fabsf(x);
+            else head_sq = __builtin_fmaf(x, x, head_sq);
+        }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) tail_abs += __shfl_xor(tail_abs, o);
-        if (lane == 0) reinterpret_cast<float*>(wtot)[wave] = tail_abs;
+        for (int o = 32; o > 0; o >>= 1) {
+            tail_abs += __shfl_xor(tail_abs, o);
+            head_sq += __shfl_xor(head_sq, o);
+        }
+        if (lane == 0) {
+            reinterpret_cast<float*>(wtot)[wave] = tail_abs;
+            reinterpret_cast<float*>(e_b)[wave] = head_sq;  // (e_b is idle until the first tile)
+        }
     }
     if (n_chunks == 1) collect(0);
     __syncthreads();
+    float head_norm = 1.0f;  // no tail: every item is a head column
     if (n_chunks > 0) {
         tail_abs = 0.f;
-        for (int w = 0; w < TPB / 64; ++w) tail_abs += reinterpret_cast<const float*>(wtot)[w];
+        head_sq = 0.f;
+        for (int w = 0; w < TPB / 64; ++w) {
+            tail_abs += reinterpret_cast<const float*>(wtot)[w];
+            head_sq += reinterpret_cast<const float*>(e_b)[w];
+        }
+        head_norm = fminf(1.0f, sqrtf(head_sq) * 1.0001f + 1e-6f);  // (fp32 summation slack)
     }
-    const float eps = row_eps(eps_base, ue - ub) + tail_abs * (1.0001f / 65536.0f);
+    const float eps = row_eps(eps_opnd * head_norm + eps_rest, ue - ub) + tail_abs * (1.0001f / 65536.0f);
     if (threadIdx.x == 0) cand_eps[r] = eps;
     const bool any_tail = n_chunks > 1 || (n_chunks == 1 && s_ne > 0);
     // single-chunk rows: thread e owns entry e for the whole row.  Its item's rater counts per tile (<= 32768 each)
@@ -632,7 +650,7 @@ void select_profile_dump() {
 
 template <class ST>
 static void launch_tail_select_t(const TailArgs& T, const ST* S, int64_t lds, int32_t n_rows, const int32_t* d_row_user,
-                                 int32_t U, int32_t kk, float eps, int32_t cap, int32_t* cand_idx, float* cand_approx,
+                                 int32_t U, int32_t kk, float eps_opnd, float eps_rest, int32_t cap, int32_t* cand_idx, float* cand_approx,
                                  int32_t* cand_cnt, float* cand_eps, hipStream_t st) {
     const size_t smem = (size_t)TCOLS * 4 + (size_t)NBINS * 4 + (size_t)EMAX * 16 + (size_t)PMAX * 2 + (TPB / 64 + 4) * 4;
     static bool attr_set = false;
@@ -640,7 +658,7 @@ static void launch_tail_select_t(const TailArgs& T, const ST* S, int64_t lds, in
         KN_HIP(hipFuncSetAttribute((const void*)k_tail_select<ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
-    k_tail_select<ST><<<n_rows, TPB, smem, st>>>(S, lds, n_rows, d_row_user, T, U, kk, eps, cap, cand_idx, cand_approx, cand_cnt, cand_eps);
+    k_tail_select<ST><<<n_rows, TPB, smem, st>>>(S, lds, n_rows, d_row_user, T, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps);
     KN_HIP(hipGetLastError());
 #ifdef KNNCF_SELECT_PROFILE
     KN_HIP(hipStreamSynchronize(st));
@@ -649,7 +667,7 @@ static void launch_tail_select_t(const TailArgs& T, const ST* S, int64_t lds, in
 }
 
 void launch_tail_select(const Train& tr, const int32_t* d_colmap, bool has_tail, const void* S, bool s_fp16, int64_t lds,
-                        int32_t n_rows, const int32_t* d_row_user, int32_t k, float eps, int32_t cap,
+                        int32_t n_rows, const int32_t* d_row_user, int32_t k, float eps_opnd, float eps_rest, int32_t cap,
                         int32_t* cand_idx, float* cand_approx, int32_t* cand_cnt, float* cand_eps, hipStream_t st) {
     if (n_rows <= 0) return;
     const int32_t U = tr.U;
@@ -659,8 +677,8 @@ void launch_tail_select(const Train& tr, const int32_t* d_colmap, bool has_tail,
     static const bool debug_no_tail = getenv("KNNCF_DEBUG_NO_TAIL") != nullptr;  // timing experiments only: wrong results
     if (debug_no_tail) has_tail = false;
     TailArgs T{tr.u_ptr.p, tr.s_col.p, tr.s_pre.p, d_colmap, tr.i_ptr.p, tr.it_pack.p, (uint32_t)(tr.n * 4), tr.it_tile.p, tr.tile_stride, has_tail ? 1 : 0};
-    if (s_fp16) launch_tail_select_t(T, static_cast<const _Float16*>(S), lds, n_rows, d_row_user, U, kk, eps, cap, cand_idx, cand_approx, cand_cnt, cand_eps, st);
-    else launch_tail_select_t(T, static_cast<const float*>(S), lds, n_rows, d_row_user, U, kk, eps, cap, cand_idx, cand_approx, cand_cnt, cand_eps, st);
+    if (s_fp16) launch_tail_select_t(T, static_cast<const _Float16*>(S), lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, st);
+    else launch_tail_select_t(T, static_cast<const float*>(S), lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, st);
 }
 
 }  // namespace knncf
