@@ -111,6 +111,8 @@ struct DArr {
         n = 0;
     }
     void alloc(size_t count) {
+        if (p && count == n && count > 0) return;  // same size as before (a re-fit of the same shape): keep the buffer —
+                                                   // hipFree synchronises the device and hipMalloc costs ~0.1-1 ms
         release();
         n = count;
         if (count == 0) count = 1;

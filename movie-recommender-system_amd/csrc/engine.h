@@ -83,7 +83,11 @@ struct PrepScratch {
     DArr<uint32_t> perm_f;
     DArr<uint32_t> status;  // [4] device status words
     DArr<double> dsum;      // small reduction scratch
+    // side streams for the three independent item folds of prep_commit (created on first use)
+    hipStream_t aux[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     void release_all();
+    ~PrepScratch();
 };
 
 // K0 + K1 + owned part of K2/K3.  Throws Error on invalid data.
