@@ -232,8 +232,8 @@ int32_t choose_head(knncf_handle* h, int32_t rows_total) {
     } else if (h->cfg.head_items > 0) {
         H = (int32_t)std::min<int64_t>(h->cfg.head_items, I);
     } else {
-        const double RATE_DENSE = 1.4e15;   // marginal flop/s of k_gemm_nt_bf16 per extra dense column (measured)
-        const double RATE_SPARSE = 8.6e11;  // marginal tail pair products per second through LDS atomics (k_tail_select, measured)
+        const double RATE_DENSE = 9.5e14;   // marginal flop/s of k_gemm_nt_bf16 per extra dense column (measured)
+        const double RATE_SPARSE = 1.8e12;  // marginal tail pair products per second through LDS atomics (k_tail_select, measured)
         const double frac = (double)rows_total / (double)tr.U;
         const double U_pad = (double)round_up(tr.U, 256);
         double best = 1e300;
