@@ -218,6 +218,8 @@ def main():
             "roofline": kernels[dominant],  # the dominant kernel of THIS run (by summed launch time)
             "roofline_all": kernels,
             "stage_ms_per_step": {k_: tm[k_] / steps for k_ in ("prep_ms", "densify_ms", "gemm_ms", "tail_ms", "select_ms", "rerank_ms", "predict_ms")},
+            # the prediction stage alone (dense-id lookup, row sort, weighted-sum prediction, MAE reduction)
+            "predict_stage_predictions_per_s": n_test * steps / (tm["predict_ms"] / 1e3) if tm["predict_ms"] > 0 else None,
             "shortlist_mean": tm["shortlist_total"] / max(1, steps * eng.num_users),
             "fallback_rows_per_step": tm["fallback_rows"] / steps,
             "hybrid": {"head_items": tm["head_items"], "tail_pair_updates_per_step": tm["tail_pair_updates"] / steps},

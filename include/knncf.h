@@ -171,6 +171,28 @@ typedef struct knncf_shard_view {
 int knncf_shard_view_get(knncf_handle* h, knncf_shard_view* out);
 int knncf_shard_commit(knncf_handle* h);
 
+/* ---- loader and on-disk cache --------------------------------- */
+/* `load` shared/predictions.scala:35-49 as a multithreaded host parser: the line is split on `separator` (literal),
+ * columns are trimmed, a line is kept iff column 0 parses as an Int (headers are dropped silently); columns 1 and 2
+ * of a kept line must parse (the reference throws; here: KNNCF_E_INVALID with "<path>:<line>: ..." in err).  Rows
+ * come back in FILE ORDER.  threads <= 0: one per hardware thread.  Release with knncf_free_ratings. */
+typedef struct knncf_ratings {
+    int64_t n;
+    int32_t* users;
+    int32_t* items;
+    double* ratings;
+} knncf_ratings;
+int knncf_load_file(const char* path, const char* separator, int threads, knncf_ratings* out, char* err, int err_cap);
+void knncf_free_ratings(knncf_ratings* r);
+
+/* Checkpoint / resume of the expensive part of a fit: the U x k neighbour table (ids, fp64 similarities, build
+ * sequence numbers).  save: every neighbourhood built so far.  load: the handle must be fitted on the same training
+ * rows with the same k and similarity (checked with a fingerprint of the users, row extents and means:
+ * KNNCF_E_STATE otherwise); afterwards getNeighbors / getSimilarity / predictions use the loaded lists and only
+ * users that were not built at save time are built on demand. */
+int knncf_neighbors_save(knncf_handle* h, const char* path);
+int knncf_neighbors_load(knncf_handle* h, const char* path);
+
 /* ---- introspection for bench / tests -------------------------------------- */
 int knncf_get_timings(const knncf_handle* h, knncf_timings* out);
 int knncf_reset_timings(knncf_handle* h);

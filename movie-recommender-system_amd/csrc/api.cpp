@@ -2,6 +2,7 @@
 // scalar queries.  No CPU arithmetic path exists here: every number an entry point returns was
 // produced by the HIP kernels (prep.hip, gemm.hip, select.hip, predict.hip).
 #include <math.h>
+#include <stdio.h>
 #include <string.h>
 
 #include <algorithm>
@@ -548,6 +549,108 @@ void do_recommend(knncf_handle* h, int predictor, int32_t user, int32_t n, int32
     *count = m;
 }
 
+// ---- checkpoint / resume of the neighbour table ------------------------------------------------------
+struct NbrFileHeader {
+    char magic[8];  // "KNNCFNB1"
+    int32_t U, kcap, k, similarity;
+    int64_t n;
+    uint64_t fingerprint;
+    int64_t epoch;
+};
+
+// FNV-1a over what identifies "the same fit": raw user ids in dense order, row extents, user means
+uint64_t fit_fingerprint(knncf_handle* h) {
+    Train& tr = h->tr;
+    std::vector<int32_t> uid(tr.U);
+    std::vector<int64_t> ptr((size_t)tr.U + 1);
+    std::vector<double> avg(tr.U);
+    KN_HIP(hipMemcpyAsync(uid.data(), tr.uid.p, (size_t)tr.U * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    KN_HIP(hipMemcpyAsync(ptr.data(), tr.u_ptr.p, ((size_t)tr.U + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    KN_HIP(hipMemcpyAsync(avg.data(), tr.user_avg.p, (size_t)tr.U * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    KN_HIP(hipStreamSynchronize(h->stream));
+    uint64_t x = 1469598103934665603ull;
+    auto mix = [&](const void* p, size_t bytes) {
+        const unsigned char* c = static_cast<const unsigned char*>(p);
+        for (size_t i = 0; i < bytes; ++i) { x ^= c[i]; x *= 1099511628211ull; }
+    };
+    mix(uid.data(), uid.size() * sizeof(int32_t));
+    mix(ptr.data(), ptr.size() * sizeof(int64_t));
+    mix(avg.data(), avg.size() * sizeof(double));
+    return x;
+}
+
+void do_neighbors_save(knncf_handle* h, const char* path) {
+    require_fitted(h);
+    KN_REQUIRE(path, KNNCF_E_INVALID, "null path");
+    KN_REQUIRE(h->cfg.shard_count == 1, KNNCF_E_UNSUPPORTED, "neighbour checkpoints are written by unsharded handles");
+    Train& tr = h->tr;
+    NeighborTable& nt = h->nt;
+    NbrFileHeader hd{};
+    memcpy(hd.magic, "KNNCFNB1", 8);
+    hd.U = tr.U; hd.kcap = nt.kcap; hd.k = nt.k; hd.similarity = h->cfg.similarity; hd.n = tr.n;
+    hd.fingerprint = fit_fingerprint(h);
+    hd.epoch = h->epoch;
+    const size_t cells = (size_t)tr.U * (size_t)std::max(nt.kcap, 1);
+    std::vector<int32_t> cnt(tr.U), idx(cells);
+    std::vector<int64_t> seq(tr.U);
+    std::vector<double> sim(cells);
+    KN_HIP(hipMemcpyAsync(cnt.data(), nt.cnt.p, cnt.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    KN_HIP(hipMemcpyAsync(seq.data(), nt.seq.p, seq.size() * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    KN_HIP(hipMemcpyAsync(idx.data(), nt.idx.p, idx.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    KN_HIP(hipMemcpyAsync(sim.data(), nt.sim.p, sim.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    KN_HIP(hipStreamSynchronize(h->stream));
+    FILE* f = fopen(path, "wb");
+    KN_REQUIRE(f, KNNCF_E_INVALID, std::string("cannot create ") + path);
+    bool ok = fwrite(&hd, sizeof hd, 1, f) == 1 && fwrite(cnt.data(), sizeof(int32_t), cnt.size(), f) == cnt.size() &&
+              fwrite(seq.data(), sizeof(int64_t), seq.size(), f) == seq.size() &&
+              fwrite(idx.data(), sizeof(int32_t), idx.size(), f) == idx.size() &&
+              fwrite(sim.data(), sizeof(double), sim.size(), f) == sim.size();
+    ok = (fclose(f) == 0) && ok;
+    KN_REQUIRE(ok, KNNCF_E_INVALID, std::string("short write to ") + path);
+}
+
+void do_neighbors_load(knncf_handle* h, const char* path) {
+    require_fitted(h);
+    KN_REQUIRE(path, KNNCF_E_INVALID, "null path");
+    KN_REQUIRE(h->cfg.shard_count == 1, KNNCF_E_UNSUPPORTED, "neighbour checkpoints are read by unsharded handles");
+    Train& tr = h->tr;
+    NeighborTable& nt = h->nt;
+    FILE* f = fopen(path, "rb");
+    KN_REQUIRE(f, KNNCF_E_INVALID, std::string("cannot open ") + path);
+    NbrFileHeader hd{};
+    bool ok = fread(&hd, sizeof hd, 1, f) == 1 && memcmp(hd.magic, "KNNCFNB1", 8) == 0;
+    if (!ok) { fclose(f); throw Error(KNNCF_E_INVALID, std::string(path) + ": not a neighbour checkpoint"); }
+    if (hd.U != tr.U || hd.kcap != nt.kcap || hd.k != nt.k || hd.similarity != h->cfg.similarity || hd.n != tr.n ||
+        hd.fingerprint != fit_fingerprint(h)) {
+        fclose(f);
+        throw Error(KNNCF_E_STATE, std::string(path) + ": checkpoint of a different fit (users, ratings, k or similarity differ)");
+    }
+    const size_t cells = (size_t)tr.U * (size_t)std::max(nt.kcap, 1);
+    std::vector<int32_t> cnt(tr.U), idx(cells);
+    std::vector<int64_t> seq(tr.U);
+    std::vector<double> sim(cells);
+    ok = fread(cnt.data(), sizeof(int32_t), cnt.size(), f) == cnt.size() && fread(seq.data(), sizeof(int64_t), seq.size(), f) == seq.size() &&
+         fread(idx.data(), sizeof(int32_t), idx.size(), f) == idx.size() && fread(sim.data(), sizeof(double), sim.size(), f) == sim.size();
+    fclose(f);
+    KN_REQUIRE(ok, KNNCF_E_INVALID, std::string(path) + ": truncated checkpoint");
+    hipStream_t st = h->stream;
+    KN_HIP(hipMemcpyAsync(nt.cnt.p, cnt.data(), cnt.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    KN_HIP(hipMemcpyAsync(nt.seq.p, seq.data(), seq.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    KN_HIP(hipMemcpyAsync(nt.idx.p, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    KN_HIP(hipMemcpyAsync(nt.sim.p, sim.data(), sim.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    // the id-sorted copies the prediction streams: for every user that has a list
+    std::vector<int32_t> built;
+    for (int32_t u = 0; u < tr.U; ++u)
+        if (seq[u] >= 0) built.push_back(u);
+    if (!built.empty() && nt.kcap > 0) {
+        h->build_list.ensure(tr.U);
+        KN_HIP(hipMemcpyAsync(h->build_list.p, built.data(), built.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        launch_sort_neighbors(nt, (int32_t)built.size(), h->build_list.p, st);
+    }
+    KN_HIP(hipStreamSynchronize(st));
+    h->epoch = std::max<int64_t>(hd.epoch, 1);
+}
+
 }  // namespace
 
 extern "C" {
@@ -801,6 +904,14 @@ int knncf_predict(knncf_handle* h, int predictor, int32_t user, int32_t item, do
 
 int knncf_recommend(knncf_handle* h, int predictor, int32_t user, int32_t n, int32_t* items, double* predictions, int32_t* count) {
     return guarded(h, [&] { do_recommend(h, predictor, user, n, items, predictions, count); });
+}
+
+int knncf_neighbors_save(knncf_handle* h, const char* path) {
+    return guarded(h, [&] { do_neighbors_save(h, path); });
+}
+
+int knncf_neighbors_load(knncf_handle* h, const char* path) {
+    return guarded(h, [&] { do_neighbors_load(h, path); });
 }
 
 int knncf_mae_device(knncf_handle* h, int predictor, const int32_t* d_users, const int32_t* d_items,

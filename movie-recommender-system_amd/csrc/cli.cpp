@@ -61,45 +61,19 @@ bool parse_int(const std::string& s, int32_t* out) {
     return true;
 }
 
-// load shared/predictions.scala:35-49: split on the separator (used literally here; the reference passes
-// it to String.split as a regex, "\t" and "," mean the same either way), trim every column, keep the line
-// iff column 0 parses as an Int (header lines are dropped silently), columns 1 and 2 must then parse
-// (the reference throws NumberFormatException / ArrayIndexOutOfBounds: we fail loudly too)
+// load shared/predictions.scala:35-49 through the library's multithreaded parser (csrc/loader.cpp): header and
+// non-numeric-first-column lines are dropped silently, a kept line with a bad column 1 or 2 fails loudly
 bool load_ratings(const std::string& path, const std::string& sep, Ratings* out, std::string* err) {
-    std::ifstream f(path);
-    if (!f) { *err = "cannot open " + path; return false; }
-    std::string line;
-    int64_t lineno = 0;
-    while (std::getline(f, line)) {
-        ++lineno;
-        if (!line.empty() && line.back() == '\r') line.pop_back();
-        std::vector<std::string> cols;
-        size_t pos = 0;
-        while (true) {
-            size_t q = sep.empty() ? std::string::npos : line.find(sep, pos);
-            if (q == std::string::npos) { cols.push_back(line.substr(pos)); break; }
-            cols.push_back(line.substr(pos, q - pos));
-            pos = q + sep.size();
-        }
-        while (cols.size() > 1 && cols.back().empty()) cols.pop_back();  // String.split drops trailing empties
-        int32_t u;
-        if (!parse_int(trim(cols[0]), &u)) continue;
-        int32_t i;
-        char* endp = nullptr;
-        if (cols.size() < 3 || !parse_int(trim(cols[1]), &i)) {
-            *err = path + ":" + std::to_string(lineno) + ": malformed rating row";
-            return false;
-        }
-        std::string rs = trim(cols[2]);
-        double r = strtod(rs.c_str(), &endp);
-        if (rs.empty() || *endp != '\0') {
-            *err = path + ":" + std::to_string(lineno) + ": malformed rating value";
-            return false;
-        }
-        out->users.push_back(u);
-        out->items.push_back(i);
-        out->ratings.push_back(r);
+    knncf_ratings r;
+    char msg[512] = {0};
+    if (knncf_load_file(path.c_str(), sep.c_str(), 0, &r, msg, (int)sizeof msg) != KNNCF_OK) {
+        *err = msg;
+        return false;
     }
+    out->users.assign(r.users, r.users + r.n);
+    out->items.assign(r.items, r.items + r.n);
+    out->ratings.assign(r.ratings, r.ratings + r.n);
+    knncf_free_ratings(&r);
     return true;
 }
 

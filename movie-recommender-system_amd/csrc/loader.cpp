@@ -1,0 +1,211 @@
+// loader.cpp — `load` shared/predictions.scala:35-49 as a multithreaded host parser (at ml-25m the
+// reference's parse time dwarfs the GPU time).  Semantics of the reference, line by line:
+//   * split the line on the separator, trim every column (String.trim: code points <= U+0020);
+//   * keep the line iff column 0 parses as an Int (`toInt` :27-33 wraps the NumberFormatException): header lines
+//     and garbage are dropped SILENTLY;
+//   * columns 1 and 2 of a kept line must parse (the reference throws NumberFormatException /
+//     ArrayIndexOutOfBoundsException: this loader fails loudly with the line number); further columns (timestamp)
+//     are ignored.
+// The file is read once, cut into byte ranges at line boundaries, parsed by `threads` workers into private arrays and
+// concatenated in file order (the order is part of the reference's semantics: SURVEY N2/N4).
+#include <errno.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/knncf.h"
+
+namespace {
+
+struct Chunk {
+    std::vector<int32_t> users, items;
+    std::vector<double> ratings;
+    int64_t bad_offset = -1;  // byte offset of the first malformed kept line
+    const char* bad_what = nullptr;
+};
+
+inline bool is_space(unsigned char c) { return c <= ' '; }
+
+// Scala's s.toInt on a trimmed column: optional sign, decimal digits only, must fit an Int
+inline bool parse_int(const char* b, const char* e, int32_t* out) {
+    while (b < e && is_space((unsigned char)*b)) ++b;
+    while (e > b && is_space((unsigned char)e[-1])) --e;
+    if (b >= e) return false;
+    bool neg = false;
+    if (*b == '-' || *b == '+') { neg = *b == '-'; ++b; }
+    if (b >= e) return false;
+    int64_t v = 0;
+    for (; b < e; ++b) {
+        if (*b < '0' || *b > '9') return false;
+        v = v * 10 + (*b - '0');
+        if (v > 2147483648ll) return false;
+    }
+    if (neg) v = -v;
+    if (v < -2147483648ll || v > 2147483647ll) return false;
+    *out = (int32_t)v;
+    return true;
+}
+
+// Scala's s.toDouble on a trimmed column (java.lang.Double.parseDouble): strtod over exactly the column
+inline bool parse_double(const char* b, const char* e, double* out) {
+    while (b < e && is_space((unsigned char)*b)) ++b;
+    while (e > b && is_space((unsigned char)e[-1])) --e;
+    if (b >= e) return false;
+    char buf[64];
+    const size_t len = (size_t)(e - b);
+    if (len >= sizeof buf) return false;
+    memcpy(buf, b, len);
+    buf[len] = '\0';
+    char* endp = nullptr;
+    const double v = strtod(buf, &endp);
+    if (endp != buf + len) return false;
+    *out = v;
+    return true;
+}
+
+void parse_range(const char* data, int64_t begin, int64_t end, const char* sep, size_t sep_len, Chunk* out) {
+    int64_t pos = begin;
+    while (pos < end) {
+        const char* line = data + pos;
+        const char* nl = (const char*)memchr(line, '\n', (size_t)(end - pos));
+        const char* le = nl ? nl : data + end;
+        const int64_t next = nl ? (nl - data) + 1 : end;
+        if (le > line && le[-1] == '\r') --le;
+        // columns 0, 1, 2 (String.split drops trailing empty strings: an empty 3rd column does not exist)
+        const char* cb[3];
+        const char* ce[3];
+        int ncol = 0;
+        const char* p = line;
+        while (ncol < 3) {
+            const char* q = nullptr;
+            if (sep_len > 0 && (size_t)(le - p) >= sep_len) {
+                for (const char* s = p; s + sep_len <= le; ++s)
+                    if (memcmp(s, sep, sep_len) == 0) { q = s; break; }
+            }
+            cb[ncol] = p;
+            ce[ncol] = q ? q : le;
+            ++ncol;
+            if (!q) break;
+            p = q + sep_len;
+        }
+        int32_t u;
+        if (parse_int(cb[0], ce[0], &u)) {
+            // trailing empties dropped: a kept line needs non-empty columns 1 and 2
+            int32_t i = 0;
+            double r = 0;
+            if (ncol < 3 || !parse_int(cb[1], ce[1], &i)) {
+                if (out->bad_offset < 0) { out->bad_offset = pos; out->bad_what = "malformed rating row"; }
+                return;
+            }
+            if (!parse_double(cb[2], ce[2], &r)) {
+                if (out->bad_offset < 0) { out->bad_offset = pos; out->bad_what = "malformed rating value"; }
+                return;
+            }
+            out->users.push_back(u);
+            out->items.push_back(i);
+            out->ratings.push_back(r);
+        }
+        pos = next;
+    }
+}
+
+void set_err(char* err, int cap, const std::string& msg) {
+    if (err && cap > 0) snprintf(err, (size_t)cap, "%s", msg.c_str());
+}
+
+}  // namespace
+
+extern "C" {
+
+int knncf_load_file(const char* path, const char* separator, int threads, knncf_ratings* out, char* err, int err_cap) {
+    if (!path || !separator || !out) { set_err(err, err_cap, "null argument"); return KNNCF_E_INVALID; }
+    out->n = 0;
+    out->users = out->items = nullptr;
+    out->ratings = nullptr;
+    FILE* f = fopen(path, "rb");
+    if (!f) { set_err(err, err_cap, std::string("cannot open ") + path + ": " + strerror(errno)); return KNNCF_E_INVALID; }
+    std::vector<char> data;
+    {
+        fseek(f, 0, SEEK_END);
+        const long sz = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        if (sz > 0) {
+            data.resize((size_t)sz);
+            const size_t got = fread(data.data(), 1, (size_t)sz, f);
+            data.resize(got);
+        } else {  // not seekable (a pipe): read to the end
+            char buf[1 << 16];
+            size_t got;
+            while ((got = fread(buf, 1, sizeof buf, f)) > 0) data.insert(data.end(), buf, buf + got);
+        }
+        fclose(f);
+    }
+    const int64_t size = (int64_t)data.size();
+    int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    if (nt > 64) nt = 64;
+    if (size < (1 << 20)) nt = 1;
+    // byte ranges that start right after a newline
+    std::vector<int64_t> cut(nt + 1, size);
+    cut[0] = 0;
+    for (int t = 1; t < nt; ++t) {
+        int64_t p = size * t / nt;
+        while (p < size && data[(size_t)p - 1] != '\n') ++p;
+        cut[t] = p;
+    }
+    for (int t = 1; t <= nt; ++t) cut[t] = std::max(cut[t], cut[t - 1]);
+    std::vector<Chunk> chunks(nt);
+    const size_t sep_len = strlen(separator);
+    std::vector<std::thread> workers;
+    for (int t = 1; t < nt; ++t)
+        workers.emplace_back(parse_range, data.data(), cut[t], cut[t + 1], separator, sep_len, &chunks[t]);
+    parse_range(data.data(), cut[0], cut[1], separator, sep_len, &chunks[0]);
+    for (auto& w : workers) w.join();
+    int64_t total = 0;
+    for (int t = 0; t < nt; ++t) {
+        if (chunks[t].bad_offset >= 0) {  // the first malformed line in file order (earlier chunks are complete)
+            int64_t lineno = 1;
+            for (int64_t p = 0; p < chunks[t].bad_offset; ++p) lineno += data[(size_t)p] == '\n';
+            set_err(err, err_cap, std::string(path) + ":" + std::to_string(lineno) + ": " + chunks[t].bad_what);
+            return KNNCF_E_INVALID;
+        }
+        total += (int64_t)chunks[t].users.size();
+    }
+    const size_t cnt = total > 0 ? (size_t)total : 1;
+    out->users = (int32_t*)malloc(cnt * sizeof(int32_t));
+    out->items = (int32_t*)malloc(cnt * sizeof(int32_t));
+    out->ratings = (double*)malloc(cnt * sizeof(double));
+    if (!out->users || !out->items || !out->ratings) {
+        knncf_free_ratings(out);
+        set_err(err, err_cap, "out of host memory");
+        return KNNCF_E_NOMEM;
+    }
+    int64_t at = 0;
+    for (int t = 0; t < nt; ++t) {
+        const size_t m = chunks[t].users.size();
+        if (m) {
+            memcpy(out->users + at, chunks[t].users.data(), m * sizeof(int32_t));
+            memcpy(out->items + at, chunks[t].items.data(), m * sizeof(int32_t));
+            memcpy(out->ratings + at, chunks[t].ratings.data(), m * sizeof(double));
+        }
+        at += (int64_t)m;
+    }
+    out->n = total;
+    return KNNCF_OK;
+}
+
+void knncf_free_ratings(knncf_ratings* r) {
+    if (!r) return;
+    free(r->users);
+    free(r->items);
+    free(r->ratings);
+    r->users = r->items = nullptr;
+    r->ratings = nullptr;
+    r->n = 0;
+}
+
+}  // extern "C"

@@ -338,7 +338,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_predict_knn_rows(PredArgs A, int
         // up to G consecutive active rows of this user
         int rows[G];
         uint32_t bbase[G], rbase[G];
-        int ng = 0;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             rows[g] = -1;
@@ -348,7 +347,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_predict_knn_rows(PredArgs A, int
                 rows[g] = r;
                 bbase[g] = (uint32_t)__builtin_amdgcn_readlane(my_i, r) * ibw;  // word offset of the item's bitmap row
                 rbase[g] = (uint32_t)__builtin_amdgcn_readlane((int)my_rb, r);
-                ++ng;
                 ++r;
             }
         }

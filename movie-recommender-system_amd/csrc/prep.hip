@@ -27,10 +27,10 @@ void PrepScratch::release_all() {
 
 PrepScratch::~PrepScratch() {
     for (int i = 0; i < 2; ++i) {
-        if (aux[i]) hipStreamDestroy(aux[i]);
-        if (ev_join[i]) hipEventDestroy(ev_join[i]);
+        if (aux[i]) (void)hipStreamDestroy(aux[i]);
+        if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
     }
-    if (ev_fork) hipEventDestroy(ev_fork);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
 }
 
 // ---- K0: ids ---------------------------------------------------------------------------

@@ -32,6 +32,31 @@ class Config(C.Structure):
                 ("workspace_bytes", C.c_int64), ("flags", C.c_uint32), ("head_items", C.c_uint32)]
 
 
+class Ratings(C.Structure):
+    """knncf_ratings of include/knncf.h"""
+    _fields_ = [("n", C.c_int64), ("users", C.POINTER(C.c_int32)), ("items", C.POINTER(C.c_int32)),
+                ("ratings", C.POINTER(C.c_double))]
+
+
+def load_file(path, separator="\t", threads=0):
+    """`load` shared/predictions.scala:35-49 through the library's multithreaded parser: (users, items, ratings) in
+    file order.  No GPU needed."""
+    L = load_library()
+    r = Ratings()
+    err = C.create_string_buffer(512)
+    st = L.knncf_load_file(os.fsencode(path), separator.encode(), threads, C.byref(r), err, len(err))
+    if st != 0:
+        raise KnncfError(st, err.value.decode(errors="replace"))
+    try:
+        n = r.n
+        u = np.ctypeslib.as_array(r.users, shape=(max(n, 1),))[:n].copy()
+        i = np.ctypeslib.as_array(r.items, shape=(max(n, 1),))[:n].copy()
+        x = np.ctypeslib.as_array(r.ratings, shape=(max(n, 1),))[:n].copy()
+    finally:
+        L.knncf_free_ratings(C.byref(r))
+    return u, i, x
+
+
 class Timings(C.Structure):
     _fields_ = [("prep_ms", C.c_double), ("densify_ms", C.c_double), ("gemm_ms", C.c_double),
                 ("tail_ms", C.c_double), ("select_ms", C.c_double), ("rerank_ms", C.c_double), ("predict_ms", C.c_double),
@@ -59,7 +84,7 @@ EXPORTS = [
     "knncf_knn_similarity", "knncf_neighbors", "knncf_predict", "knncf_recommend", "knncf_predict_batch",
     "knncf_predict_batch_device", "knncf_mae", "knncf_mae_device", "knncf_shard_view_get",
     "knncf_shard_commit", "knncf_get_timings", "knncf_reset_timings", "knncf_reset_neighbors",
-    "knncf_set_k",
+    "knncf_set_k", "knncf_load_file", "knncf_free_ratings", "knncf_neighbors_save", "knncf_neighbors_load",
 ]
 
 
@@ -133,6 +158,11 @@ def load_library():
     L.knncf_reset_timings.argtypes = [C.c_void_p]
     L.knncf_reset_neighbors.argtypes = [C.c_void_p]
     L.knncf_set_k.argtypes = [C.c_void_p, C.c_int32]
+    L.knncf_load_file.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(Ratings), C.c_char_p, C.c_int]
+    L.knncf_free_ratings.argtypes = [C.POINTER(Ratings)]
+    L.knncf_free_ratings.restype = None
+    L.knncf_neighbors_save.argtypes = [C.c_void_p, C.c_char_p]
+    L.knncf_neighbors_load.argtypes = [C.c_void_p, C.c_char_p]
     _lib = L
     return L
 
@@ -252,6 +282,14 @@ class Engine:
 
     def predict(self, predictor, u, i):
         return self._scalar(self._lib.knncf_predict, predictor, u, i)
+
+    def neighbors_save(self, path):
+        """checkpoint of the U x k neighbour table (knncf_neighbors_save)"""
+        self._check(self._lib.knncf_neighbors_save(self._h, os.fsencode(path)))
+
+    def neighbors_load(self, path):
+        """resume from a checkpoint written by a handle fitted on the same data with the same k (knncf_neighbors_load)"""
+        self._check(self._lib.knncf_neighbors_load(self._h, os.fsencode(path)))
 
     def recommend(self, predictor, user, n):
         """recommendations(train, predictor)(user, n) shared/predictions.scala:651-674: (item ids, predictions)"""
