@@ -114,7 +114,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)  # nccl == RCCL on ROCm
 
-    importlib.import_module(PKG + ".build").build()
+    # the in-tree library is prebuilt; if anything is stale, ONE rank rebuilds it while the others wait
+    if rank == 0:
+        importlib.import_module(PKG + ".build").build()
+    if dist is not None:
+        dist.barrier()
+    if rank != 0:
+        importlib.import_module(PKG + ".build").build()
     kn = importlib.import_module(PKG + ".knncf")
     synth = importlib.import_module(PKG + ".synth")
     sharded = importlib.import_module(PKG + ".sharded")
