@@ -112,6 +112,10 @@ class ShardedKnn:
         allr = allr.cpu().view(self.world, 4).tolist()
         _all_gather_segments(self.dist, [t["user_avg"], t["user_norm"]], ulo, uhi, [(a, b) for a, b, _, _ in allr])
         _all_gather_segments(self.dist, [t["dev"], t["pre"]], nlo, nhi, [(c, d) for _, _, c, d in allr])
+        # the engine works on its own (non-blocking) HIP stream: the gathered segments must have landed before
+        # shard_commit launches the kernels that read them
+        if dev.type == "cuda":
+            torch.cuda.current_stream(dev).synchronize()
 
     def mae(self, predictor, users, items, ratings):
         """All-reduced MAE of the whole test set; every rank receives the same value."""
