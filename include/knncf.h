@@ -48,7 +48,9 @@ extern "C" {
 #define KNNCF_PRED_BASELINE 3     /* computePrediction :205-237 */
 #define KNNCF_PRED_BASELINE_RDD 4 /* baselinePredictorSpark :362-391 */
 #define KNNCF_PRED_KNN 5          /* predictor(train, weightedSumDeviation(train, getSimilarity(train, k, sim))) predict/kNN.scala:43-44 */
-#define KNNCF_PRED_PERSONALIZED 6 /* predictor(train, weightedSumDeviation(train, sim)) predict/Personalized.scala:61-72 */
+#define KNNCF_PRED_PERSONALIZED 6 /* predictor(train, weightedSumDeviation(train, sim)) predict/Personalized.scala:61-72, sim = the
+                                     handle's similarity itself, no neighbourhood cut.  Cosine / Jaccard keep U x U values: U <= 2048;
+                                     cosine additionally needs > 4 ratings per user, else KNNCF_E_UNSUPPORTED */
 
 #define KNNCF_FLAG_VERIFY_BOUND 1u /* check |approx - exact| <= eps on every re-ranked pair (debug) */
 /* The similarity GEMM is only a filter in front of the exact fp64 re-rank.  Default operand type is fp16

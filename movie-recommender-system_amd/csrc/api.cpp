@@ -56,6 +56,8 @@ struct knncf_handle {
     int32_t* pinned_cnt = nullptr;
     size_t pinned_cap = 0;
     SelectScratch sel;
+    NeighborTable pt;       // Personalized (no k): every non-zero similarity of every user (ids ascending, self included)
+    bool pt_ready = false;
     DArr<int32_t> reco_users, reco_items, reco_out_items;
     DArr<double> reco_pred, reco_out_preds;
     DArr<uint8_t> reco_rated;
@@ -432,6 +434,32 @@ void ensure_neighbors_for_rows(knncf_handle* h, int64_t n) {
     build_neighbors(h, count);
 }
 
+// predictor(train, weightedSumDeviation(train, sim)) with sim = adjustedCosineSimilarityFunction(train) or
+// jaccardCoefficient(train) (predict/Personalized.scala:61-72): the table of every non-zero similarity, built once per fit
+void ensure_personalized_table(knncf_handle* h) {
+    if (h->pt_ready) return;
+    Train& tr = h->tr;
+    KN_REQUIRE(h->cfg.shard_count == 1, KNNCF_E_UNSUPPORTED, "PERSONALIZED is not sharded");
+    KN_REQUIRE(tr.U <= 2048, KNNCF_E_UNSUPPORTED,
+               "PERSONALIZED with the adjusted cosine / Jaccard similarity keeps U x U similarities: built for U <= 2048 (the reference runs it at ml-100k scale)");
+    if (h->cfg.similarity == KNNCF_SIM_COSINE) {
+        std::vector<int64_t> ptr((size_t)tr.U + 1);
+        KN_HIP(hipMemcpyAsync(ptr.data(), tr.u_ptr.p, ptr.size() * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+        KN_HIP(hipStreamSynchronize(h->stream));
+        for (int32_t u = 0; u < tr.U; ++u)
+            KN_REQUIRE(ptr[u + 1] - ptr[u] > 4, KNNCF_E_UNSUPPORTED,
+                       "PERSONALIZED with the adjusted cosine: a user with <= 4 ratings makes the reference's summation order depend on its memo history pair by pair (SURVEY N6); not modelled");
+    }
+    NeighborTable& pt = h->pt;
+    pt.k = pt.kcap = tr.U;
+    const size_t cells = (size_t)tr.U * (size_t)tr.U;
+    pt.uidx.ensure(cells);
+    pt.usim.ensure(cells);
+    pt.cnt.ensure(tr.U);
+    launch_full_rows(tr, h->cfg.similarity == KNNCF_SIM_JACCARD, pt.uidx.p, pt.usim.p, pt.cnt.p, h->stream);
+    h->pt_ready = true;
+}
+
 void run_predict(knncf_handle* h, int predictor, const int32_t* d_users, const int32_t* d_items,
                  const double* d_ratings, int64_t n, double* sum_abs_err, int64_t* count, double* d_pred_out) {
     require_fitted(h);
@@ -443,10 +471,15 @@ void run_predict(knncf_handle* h, int predictor, const int32_t* d_users, const i
     if (n == 0) return;
     KN_REQUIRE(d_users && d_items, KNNCF_E_INVALID, "null test arrays");
     int kind = predictor;
+    const NeighborTable* table = &h->nt;
     if (predictor == KNNCF_PRED_PERSONALIZED) {
-        KN_REQUIRE(h->cfg.similarity == KNNCF_SIM_ONE, KNNCF_E_UNSUPPORTED,
-                   "PERSONALIZED without a neighbourhood is built for similarityOne only; use KNN with k >= U-1 for cosine");
-        kind = KNNCF_PRED_BASELINE_RDD;  // num/den = file-order mean of the item's deviations (see predict.hip)
+        if (h->cfg.similarity == KNNCF_SIM_ONE) {
+            kind = KNNCF_PRED_BASELINE_RDD;  // num/den = file-order mean of the item's deviations (see predict.hip)
+        } else {  // the adjusted cosine / the Jaccard coefficient themselves: every user is a "neighbour"
+            ensure_personalized_table(h);
+            kind = KNNCF_PRED_KNN;
+            table = &h->pt;
+        }
     }
     KN_REQUIRE(kind >= KNNCF_PRED_GLOBAL_AVG && kind <= KNNCF_PRED_KNN, KNNCF_E_INVALID, "unknown predictor");
     ensure_test_scratch(h, n);
@@ -454,7 +487,7 @@ void run_predict(knncf_handle* h, int predictor, const int32_t* d_users, const i
         Stage s(h, &h->tm.predict_ms);
         launch_dense_ids(tr, d_users, d_items, n, h->t_du.p, h->t_di.p, st);
     }
-    if (kind == KNNCF_PRED_KNN) ensure_neighbors_for_rows(h, n);
+    if (kind == KNNCF_PRED_KNN && table == &h->nt) ensure_neighbors_for_rows(h, n);
     {
         Stage s(h, &h->tm.predict_ms);
         double* pred = d_pred_out ? d_pred_out : h->t_pred.p;
@@ -467,7 +500,7 @@ void run_predict(knncf_handle* h, int predictor, const int32_t* d_users, const i
             sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.v32_a.p, sc.v32_b.p, n, 32, st);
             d_order = sc.v32_b.p;
         }
-        launch_predict(tr, &h->nt, kind, n, h->t_du.p, h->t_di.p, d_ratings, d_order, by_item, pred, h->t_err.p, h->t_owned.p,
+        launch_predict(tr, table, kind, n, h->t_du.p, h->t_di.p, d_ratings, d_order, by_item, pred, h->t_err.p, h->t_owned.p,
                        h->cfg.shard_rank == 0, st);
         if (sum_abs_err || count) {
             const int32_t nb = 1024;
@@ -492,6 +525,7 @@ void do_fit_device(knncf_handle* h, const int32_t* d_users, const int32_t* d_ite
     hipStream_t st = h->stream;
     h->fitted = h->committed = false;
     h->b_ready = false;
+    h->pt_ready = false;
     h->h_ukeys.clear(); h->h_ikeys.clear(); h->h_uid.clear();
     tr.n = n;
     {

@@ -292,25 +292,24 @@ Json run_personalized(const Args& a, const Ratings& train, const Ratings& test) 
                            .set("2.OnesMAE", Json::Num(one.mae(KNNCF_PRED_PERSONALIZED, test))));
     }
     {
-        int32_t U = 0;
-        Engine cosv(a.device, 1, KNNCF_SIM_COSINE);
+        Engine cosv(a.device, a.k, KNNCF_SIM_COSINE);
         cosv.fit(train);
-        check(cosv.h, knncf_num_users(cosv.h, &U), "num_users");
-        check(cosv.h, knncf_set_k(cosv.h, U), "set_k");  // no neighbourhood cut == every other user is a neighbour
         double s21 = 0;
         check(cosv.h, knncf_similarity(cosv.h, 2, 1, &s21), "similarity");
         out.set("P.2", Json::Obj()
                            .set("1.AdjustedCosineUser1User2", Json::Num(s21))
-                           .set("2.PredUser1Item1", Json::Num(cosv.predict(KNNCF_PRED_KNN, 1, 1)))
-                           .set("3.AdjustedCosineMAE", Json::Num(cosv.mae(KNNCF_PRED_KNN, test))));
+                           .set("2.PredUser1Item1", Json::Num(cosv.predict(KNNCF_PRED_PERSONALIZED, 1, 1)))
+                           .set("3.AdjustedCosineMAE", Json::Num(cosv.mae(KNNCF_PRED_PERSONALIZED, test))));
     }
     {
         Engine jac(a.device, a.k, KNNCF_SIM_JACCARD);
         jac.fit(train);
         double s12 = 0;
         check(jac.h, knncf_similarity(jac.h, 1, 2, &s12), "similarity");
-        Json nul;  // Jaccard-weighted prediction is not built (the reference's committed P.3 answers are stale)
-        out.set("P.3", Json::Obj().set("1.JaccardUser1User2", Json::Num(s12)).set("2.PredUser1Item1", nul).set("3.JaccardPersonalizedMAE", nul));
+        out.set("P.3", Json::Obj()
+                           .set("1.JaccardUser1User2", Json::Num(s12))
+                           .set("2.PredUser1Item1", Json::Num(jac.predict(KNNCF_PRED_PERSONALIZED, 1, 1)))
+                           .set("3.JaccardPersonalizedMAE", Json::Num(jac.mae(KNNCF_PRED_PERSONALIZED, test))));
     }
     return out;
 }

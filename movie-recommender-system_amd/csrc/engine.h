@@ -145,6 +145,9 @@ void launch_rerank(const Train& tr, NeighborTable& nt, int32_t n_rows, const int
 // exact similarities of one user against everyone (fallback + scalar queries)
 void launch_exact_row(const Train& tr, const NeighborTable& nt, int32_t user, int64_t user_seq,
                       double* d_out, hipStream_t st);
+// Personalized (no k): per user the ids (ascending, the user itself included) and fp64 values of every non-zero
+// adjusted-cosine / Jaccard similarity; d_idx / d_sim hold U x U cells, d_cnt the list lengths
+void launch_full_rows(const Train& tr, bool jaccard, int32_t* d_idx, double* d_sim, int32_t* d_cnt, hipStream_t st);
 // fresh-closure similarity of one pair (owner order = u): writes *d_out
 void launch_exact_pair(const Train& tr, int32_t u, int32_t v, double* d_out, hipStream_t st);
 

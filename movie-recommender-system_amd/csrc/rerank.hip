@@ -498,6 +498,73 @@ void launch_exact_row(const Train& tr, const NeighborTable& nt, int32_t user, in
     KN_HIP(hipGetLastError());
 }
 
+// ---- Personalized (no k): weightedSumDeviation(train, sim) with sim = the adjusted cosine or the Jaccard coefficient
+// itself (predict/Personalized.scala:61-72).  The "neighbour list" of u is every user x with sim(u, x) != 0 — u itself
+// included: when (u, i) is also a training pair, u is one of i's raters and contributes sim(u, u) — in ascending dense id,
+// which is what the prediction kernels stream.  O(U^2) pairs: the reference only runs it at ml-100k scale; so does this.
+// Cosine: every user must have more than 4 ratings (checked by the caller), so the summation order does not depend on
+// the memo history and merge_dot is the reference's sum.
+template <bool JACCARD>
+__global__ void __launch_bounds__(TPB) k_full_rows(Rows R, int32_t U, int32_t* __restrict__ out_idx, double* __restrict__ out_sim,
+                                                   int32_t* __restrict__ out_cnt) {
+    __shared__ int32_t wsum[TPB / 64];
+    __shared__ int32_t s_base;
+    const int32_t u = blockIdx.x;
+    if (u >= U) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    const int64_t pa0 = R.u_ptr[u], ea = R.u_ptr[u + 1];
+    for (int32_t v0 = 0; v0 < U; v0 += TPB) {
+        const int32_t v = v0 + threadIdx.x;
+        double s = 0.0;
+        if (v < U) {
+            if (JACCARD) {  // jaccardCoefficient :446-463: |I(u) & I(v)| / (|I(u)| + |I(v)| - |I(u) & I(v)|)
+                int64_t pa = pa0, pb = R.u_ptr[v];
+                const int64_t eb = R.u_ptr[v + 1];
+                const int64_t nv = eb - pb;
+                int64_t both = 0;
+                while (pa < ea && pb < eb) {
+                    const int32_t ca = R.s_col[pa], cb = R.s_col[pb];
+                    if (ca == cb) { ++both; ++pa; ++pb; }
+                    else if (ca < cb) ++pa;
+                    else ++pb;
+                }
+                s = (double)both / (double)((ea - pa0) + nv - both);
+            } else {
+                s = merge_dot(R, u, v);
+            }
+        }
+        // ordered compaction of the non-zero similarities of this chunk (ids ascending)
+        const bool keep = v < U && s != 0.0;
+        const unsigned long long km = __ballot(keep);
+        if (lane == 0) wsum[wave] = __popcll(km);
+        __syncthreads();
+        int32_t before = s_base;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        if (keep) {
+            const int64_t pos = (int64_t)u * U + before + __popcll(km & ((1ull << lane) - 1ull));
+            out_idx[pos] = v;
+            out_sim[pos] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int32_t tot = 0;
+            for (int w = 0; w < TPB / 64; ++w) tot += wsum[w];
+            s_base += tot;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out_cnt[u] = s_base;
+}
+
+void launch_full_rows(const Train& tr, bool jaccard, int32_t* d_idx, double* d_sim, int32_t* d_cnt, hipStream_t st) {
+    Rows R{tr.u_ptr.p, tr.s_col.p, tr.s_t.p, tr.s_pre.p, (uint32_t)(tr.n * 4), (uint32_t)(tr.n * 8)};
+    if (jaccard) k_full_rows<true><<<tr.U, TPB, 0, st>>>(R, tr.U, d_idx, d_sim, d_cnt);
+    else k_full_rows<false><<<tr.U, TPB, 0, st>>>(R, tr.U, d_idx, d_sim, d_cnt);
+    KN_HIP(hipGetLastError());
+}
+
 __global__ void k_exact_pair(Rows R, int32_t u, int32_t v, double* __restrict__ out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *out = owner_dot(R, u, v);
 }

@@ -85,7 +85,10 @@ def test_entry_points_against_oracle(cli, tmp_path, oracle, syn100k):
     assert pz["P.1"]["2.OnesMAE"] == pytest.approx(m.pipeline(oracle.SIM_ONE, -1).mae(*T), abs=1e-12)
     assert pz["P.2"]["1.AdjustedCosineUser1User2"] == m.fresh_similarity(oracle.SIM_COSINE, 2, 1)
     assert pz["P.2"]["3.AdjustedCosineMAE"] == pytest.approx(m.pipeline(oracle.SIM_COSINE, -1).mae(*T), abs=1e-9)
+    assert pz["P.2"]["2.PredUser1Item1"] == m.pipeline(oracle.SIM_COSINE, -1).predict(1, 1)
     assert pz["P.3"]["1.JaccardUser1User2"] == m.fresh_similarity(oracle.SIM_JACCARD, 1, 2)
+    assert pz["P.3"]["2.PredUser1Item1"] == m.pipeline(oracle.SIM_JACCARD, -1).predict(1, 1)
+    assert pz["P.3"]["3.JaccardPersonalizedMAE"] == pytest.approx(m.pipeline(oracle.SIM_JACCARD, -1).mae(*T), abs=1e-9)
 
     dz = run("distributed-baseline", "--master", "local[4]")
     assert dz["Meta"]["3.Master"] == "local[4]" and dz["Meta"]["4.Measurements"] == 2

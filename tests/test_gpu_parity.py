@@ -94,6 +94,21 @@ def test_random_small_cases_bitwise(kn, oracle, seed):
     jac = _engine(kn, tr, sim=kn.SIM_JACCARD)
     for a, b in zip(users[:6], users[3:9]):
         assert jac.similarity(a, b) == m.fresh_similarity(oracle.SIM_JACCARD, a, b)
+    # Personalized without a neighbourhood cut: Jaccard always; the adjusted cosine when no user has <= 4 ratings
+    # (otherwise the reference's summation order depends on its memo history pair by pair: refused, not approximated).
+    # Training pairs are predicted too: the user is then one of the item's raters and weighs in with sim(u, u).
+    pu = np.concatenate([te[0], tr[0][:12]])
+    pi = np.concatenate([te[1], tr[1][:12]])
+    want = np.array([m.pipeline(oracle.SIM_JACCARD, -1).predict(int(a), int(b)) for a, b in zip(pu, pi)])
+    np.testing.assert_array_equal(jac.predict_batch(kn.PRED_PERSONALIZED, pu, pi), want)
+    cosp = _engine(kn, tr, sim=kn.SIM_COSINE)
+    if min(np.bincount(np.unique(tr[0], return_inverse=True)[1])) > 4:
+        pc = m.pipeline(oracle.SIM_COSINE, -1)
+        want = np.array([pc.predict(int(a), int(b)) for a, b in zip(pu, pi)])
+        np.testing.assert_array_equal(cosp.predict_batch(kn.PRED_PERSONALIZED, pu, pi), want)
+    else:
+        with pytest.raises(kn.KnncfError):
+            cosp.predict_batch(kn.PRED_PERSONALIZED, pu, pi)
 
 
 @pytest.mark.parametrize("shuffle", [False, True])
@@ -119,6 +134,24 @@ def test_ml100k_shape_all_neighbours_and_predictions(kn, oracle, synth, shuffle)
         t = e.timings()
         assert t["max_bound_violation"] <= 0.0
         assert t["gemm_launches"] >= 1
+        e.close()
+
+
+def test_personalized_cosine_and_jaccard_ml100k_shape(kn, oracle, synth):
+    """predict/Personalized.scala P.2 / P.3: predictor(train, weightedSumDeviation(train, sim)) with the adjusted cosine
+    and the Jaccard coefficient themselves (no k), test rows plus some training pairs (self term), bit for bit"""
+    d = synth.syn_100k()
+    tr = (d.train.users, d.train.items, d.train.ratings)
+    te = (d.test.users, d.test.items, d.test.ratings)
+    m = oracle.Model(*tr)
+    pu = np.concatenate([te[0], tr[0][:200]])
+    pi = np.concatenate([te[1], tr[1][:200]])
+    pr = np.concatenate([te[2], tr[2][:200]])
+    for sim_o, sim_k in ((oracle.SIM_COSINE, kn.SIM_COSINE), (oracle.SIM_JACCARD, kn.SIM_JACCARD)):
+        e = _engine(kn, tr, sim=sim_k)
+        want, preds = m.pipeline(sim_o, -1).mae(pu, pi, pr, True)
+        np.testing.assert_array_equal(e.predict_batch(kn.PRED_PERSONALIZED, pu, pi), preds)
+        assert abs(e.mae(kn.PRED_PERSONALIZED, pu, pi, pr) - want) <= MAE_TOL
         e.close()
 
 
