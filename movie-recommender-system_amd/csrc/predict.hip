@@ -65,12 +65,6 @@ __device__ __forceinline__ T* uniform_ptr(T* p) {
     return reinterpret_cast<T*>(((uint64_t)hi << 32) | lo);
 }
 
-#ifdef KNNCF_PREDICT_PROFILE
-__device__ unsigned long long g_pphase[8];
-#define PPH(i) do { if (lane == 0) { const long long now_ = clock64(); atomicAdd(&g_pphase[i], (unsigned long long)(now_ - ph_t)); ph_t = now_; } } while (0)
-#else
-#define PPH(i) do {} while (0)
-#endif
 
 template <int CAP, int WAVES>  // per-wave match capacity (power of two >= kcap), waves per block
 __global__ void __launch_bounds__(WAVES * 64) k_predict_knn(PredArgs A, int64_t n, const int32_t* __restrict__ du,
@@ -84,9 +78,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_predict_knn(PredArgs A, int64_t 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t w = (int64_t)blockIdx.x * WAVES + wave;
     if (w >= n) return;
-#ifdef KNNCF_PREDICT_PROFILE
-    long long ph_t = clock64();
-#endif
     const int64_t t = order ? (int64_t)order[w] : w;
     const int32_t u = du[t], i = di[t];
     const bool mine = (u < 0) ? (unknown_owned != 0) : (u >= A.own_lo && u < A.own_hi);
@@ -112,7 +103,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_predict_knn(PredArgs A, int64_t 
         // look for neighbouring ids, so the searches share their cache sectors (the per-neighbour-row
         // searches they replace touched ~7 private sectors each and were bound by L2 sector bandwidth).
         const int64_t rb = A.i_ptr[i], re = A.i_ptr[i + 1];
-        PPH(0);
         if (A.ib_words > 0) {
             // "Which of u's neighbours rated item i, and where is that rating": item i's rater bitmap (U bits) + rank
             // prefixes answer it with one 8-byte + one 4-byte read per neighbour.  A prediction is a chain of three
@@ -196,10 +186,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_predict_knn(PredArgs A, int64_t 
                 total += __popcll(hit);
             }
         }
-        PPH(1);
-#ifdef KNNCF_PREDICT_PROFILE
-        if (lane == 0) atomicAdd(&g_pphase[6], (unsigned long long)total);
-#endif
         // order the matches by training file row (the order of ratedI(i) :508-517): rank by counting.  Lane l owns
         // the matches in slots l, l + 64, ...; every lane streams all keys (LDS broadcast reads, 4 keys per read) and
         // counts the smaller ones; then each match moves to its rank.  No dependent LDS round trips, unlike a sorting
@@ -241,7 +227,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_predict_knn(PredArgs A, int64_t 
             }
             wave_sync();
         }
-        PPH(2);
         double num = 0.0, den = 0.0;
         for (int32_t c = 0; c < total; ++c) {  // every lane folds the same sequence (LDS broadcast)
             double s = ms[c];
@@ -250,7 +235,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_predict_knn(PredArgs A, int64_t 
         }
         double wsd = (den > 0) ? num / den : 0.0;
         p = combine(ua, wsd);
-        PPH(3);
     }
     if (lane == 0) {
         pred[t] = p;
@@ -727,18 +711,6 @@ void launch_predict(const Train& tr, const NeighborTable* nt, int predictor, int
                                                                      d_abs_err, d_owned, unknown_users_owned ? 1 : 0);
     }
     KN_HIP(hipGetLastError());
-#ifdef KNNCF_PREDICT_PROFILE
-    if (predictor == KNNCF_PRED_KNN) {
-        KN_HIP(hipStreamSynchronize(st));
-        unsigned long long h[8];
-        hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pphase), sizeof(h));
-        unsigned long long tot = h[0] + h[1] + h[2] + h[3];
-        fprintf(stderr, "[predict profile] %.3e cycles/prediction; setup %.1f%% gathers %.1f%% rank %.1f%% fold %.1f%%; matches/prediction %.1f\n",
-                (double)tot / (double)n, 100.0 * h[0] / tot, 100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * h[3] / tot, (double)h[6] / (double)n);
-        memset(h, 0, sizeof(h));
-        hipMemcpyToSymbol(HIP_SYMBOL(g_pphase), h, sizeof(h));
-    }
-#endif
 }
 
 // fixed-shape reduction: block b sums elements b, b + B, ... (each thread a strided slice, then a

@@ -234,13 +234,8 @@ __device__ __forceinline__ double wave_sims(const Rows& R, lds_cu32x2 bp, PreP u
             }
         }
         const uint32_t q = valid ? c_base + s : 0x3fffffffu;  // -> byte offsets beyond both arrays
-#ifdef KNNCF_EXP_NOLOAD
-        pc[d] = (q * 2654435761u) >> 16;
-        py[d].x = q; py[d].y = 0x3ff00000u;
-#else
         pc[d] = __builtin_amdgcn_raw_buffer_load_b32(col_rsrc, (int)(q << 2), 0, 0);  // (no use of the loaded values
         py[d] = __builtin_amdgcn_raw_buffer_load_b64(pre_rsrc, (int)(q << 3), 0, 0);  //  here: a use is a wait)
-#endif
         pfl[d] = valid ? (((uint32_t)jf << 8) | (s == c_start ? 3u : 1u)) : 0u;
     };
     auto fold = [&]() {  // lane j folds candidate j's products left: the reference's `.sum` order

@@ -361,11 +361,7 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
             const int src = (int)min(j0 + j, 63u);  // wave-uniform
             const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)d_q, src) + lane;
             const uint32_t qend = (j0 + j < n_here) ? (uint32_t)__builtin_amdgcn_readlane((int)d_end, src) : 0u;
-#ifdef KNNCF_EXP_NOLOAD
-            w[j] = q < qend ? q * 2654435761u : 0u;
-#else
             w[j] = __builtin_amdgcn_raw_buffer_load_b32(pack_rsrc, q < qend ? (int)(q << 2) : -1, 0, 0);
-#endif
         }
     };
     auto apply = [&](uint32_t j0) {
