@@ -39,13 +39,12 @@ __device__ unsigned long long g_phase[16];
 // 10 % slower (and a 48 KiB-tile variant of an earlier version of this kernel 1.7x slower: tiles cost per tile).
 // __launch_bounds__(2 * TPB) caps the kernel at 128 VGPRs so that both workgroups fit.
 static constexpr int TPB = 512;
-static constexpr int NBINS = 2048;
+static constexpr int NBINS = 1024;
 static constexpr int TCOLS = SELECT_TCOLS;  // columns of the row held in LDS at a time (64 KiB)
 static constexpr int CPT = TCOLS / TPB;  // columns per thread per tile (32 = 4 groups of 8)
 static constexpr int NG = CPT / 8;
 static_assert(CPT <= 32, "the survivor mask of a thread is one 32-bit word");
 static constexpr int EMAX = 256;     // row positions whose tail entries (16 B each) are held in LDS at a time
-static constexpr bool PIPELINE_TAIL = false;  // request a tile's first pieces during the previous tile's select work (measured: no gain)
 static constexpr int PMAX = 1024;    // pieces per (chunk, tile) with a direct piece -> entry table in LDS
 static constexpr int MAXT = 16;      // tiles whose per-entry rater counts are packed into registers
 static constexpr int TAIL_ILP = 16;        // 64-rater pieces a wave keeps in flight
@@ -167,13 +166,19 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
     int32_t* itile = reinterpret_cast<int32_t*>(smem);            // [TCOLS] tail accumulator, Q7.24, cell layout of it_pack
     uint32_t* hist = reinterpret_cast<uint32_t*>(itile + TCOLS);  // [NBINS]
     float* e_x = reinterpret_cast<float*>(hist + NBINS);          // [EMAX] pre(u, item) * 2^24
-    uint32_t* e_b = reinterpret_cast<uint32_t*>(e_x + EMAX);      // [EMAX] this tile's range of the item's rater list
-    uint32_t* e_e = e_b + EMAX;                                   // [EMAX]
-    uint32_t* e_ps = e_e + EMAX;                                  // [EMAX] exclusive prefix of the 64-rater piece counts
-    int32_t* e_item = reinterpret_cast<int32_t*>(e_ps);           //   (aliased: the item of the entry, until its owner read it)
-    uint16_t* piece_e = reinterpret_cast<uint16_t*>(e_ps + EMAX); // [PMAX] entry of every piece
+    // the per-tile tables exist twice: tile t + 1's are filled while tile t is still being used (see the tile loop)
+    uint32_t* e_b0 = reinterpret_cast<uint32_t*>(e_x + EMAX);     // [2][EMAX] the tile's range of the item's rater list
+    uint32_t* e_e0 = e_b0 + 2 * EMAX;                             // [2][EMAX]
+    uint32_t* e_ps0 = e_e0 + 2 * EMAX;                            // [2][EMAX] exclusive prefix of the 64-rater piece counts
+    int32_t* e_item = reinterpret_cast<int32_t*>(e_ps0);          //   (aliased: the item of the entry, until its owner read it)
+    uint16_t* piece_e0 = reinterpret_cast<uint16_t*>(e_ps0 + 2 * EMAX);  // [2][PMAX] entry of every piece
     // (no static __shared__: the accumulator must sit at LDS address 0, its cell addresses come straight out of it_pack)
-    uint32_t* wtot = reinterpret_cast<uint32_t*>(piece_e + PMAX); // [TPB / 64]
+    uint32_t* wtot = reinterpret_cast<uint32_t*>(piece_e0 + 2 * PMAX);   // [TPB / 64]
+    uint32_t* wtot2 = wtot + TPB / 64 + 4;                        // [TPB / 64] piece counts per wave (setup)
+    uint32_t* e_b = e_b0;
+    uint32_t* e_e = e_e0;
+    uint32_t* e_ps = e_ps0;
+    uint16_t* piece_e = piece_e0;
     float& s_thr = *reinterpret_cast<float*>(wtot + TPB / 64);
     uint32_t& s_count = wtot[TPB / 64 + 1];
     int32_t& s_ne = *reinterpret_cast<int32_t*>(wtot + TPB / 64 + 2);
@@ -235,7 +240,7 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
         }
         if (lane == 0) {
             reinterpret_cast<float*>(wtot)[wave] = tail_abs;
-            reinterpret_cast<float*>(e_b)[wave] = head_sq;  // (e_b is idle until the first tile)
+            reinterpret_cast<float*>(e_b0)[wave] = head_sq;  // (idle until the first setup)
         }
     }
     if (n_chunks == 1) collect(0);
@@ -246,7 +251,7 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
         head_sq = 0.f;
         for (int w = 0; w < TPB / 64; ++w) {
             tail_abs += reinterpret_cast<const float*>(wtot)[w];
-            head_sq += reinterpret_cast<const float*>(e_b)[w];
+            head_sq += reinterpret_cast<const float*>(e_b0)[w];
         }
         head_norm = fminf(1.0f, sqrtf(head_sq) * 1.0001f + 1e-6f);  // (fp32 summation slack)
     }
@@ -283,7 +288,12 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
     uint32_t d_q = 0, d_end = 0;
     float d_x = 0.f;
     uint32_t w[ILP];
-    auto setup = [&](int tile) {
+    // setup of a tile = two halves around ONE barrier: (a) every entry's range inside the tile and the piece counts per
+    // wave, (b) the exclusive prefix, the piece -> entry table and this wave's share [p_lo, p_hi) of the pieces.
+    // `buf` selects the table copy.  For single-chunk rows the halves of tile t + 1 sit around a barrier tile t needs
+    // anyway, so the setup costs no barrier of its own.
+    uint32_t su_np = 0, su_incl = 0;  // carried from half (a) to half (b)
+    auto setup_a = [&](int tile, int buf) {
         ne = s_ne;
         uint32_t np = 0;
         if ((int32_t)threadIdx.x < ne) {
@@ -300,28 +310,29 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
                 qb = tb[0];
                 cnt = tb[1] - qb;
             }
-            e_b[threadIdx.x] = qb;
-            e_e[threadIdx.x] = qb + cnt;
+            e_b0[buf * EMAX + threadIdx.x] = qb;
+            e_e0[buf * EMAX + threadIdx.x] = qb + cnt;
             np = (cnt + 63u) >> 6;
         }
-        const uint32_t incl = wave_incl_scan(np);
-        if (lane == 63 && wave < EMAX / 64) wtot[wave] = incl;
-        __syncthreads();
+        su_np = np;
+        su_incl = wave_incl_scan(np);
+        if (lane == 63 && wave < EMAX / 64) wtot2[wave] = su_incl;
+    };
+    auto setup_b = [&](int buf) {
         uint32_t off = 0;
         P = 0;
 #pragma unroll
         for (int w2 = 0; w2 < EMAX / 64; ++w2) {
-            const uint32_t sw = wtot[w2];
+            const uint32_t sw = wtot2[w2];
             P += sw;
             if (w2 < wave) off += sw;
         }
         if ((int32_t)threadIdx.x < ne) {
-            const uint32_t excl = off + incl - np;
-            e_ps[threadIdx.x] = excl;
+            const uint32_t excl = off + su_incl - su_np;
+            e_ps0[buf * EMAX + threadIdx.x] = excl;
             if (P <= PMAX)
-                for (uint32_t k2 = 0; k2 < np; ++k2) piece_e[excl + k2] = (uint16_t)threadIdx.x;
+                for (uint32_t k2 = 0; k2 < su_np; ++k2) piece_e0[buf * PMAX + excl + k2] = (uint16_t)threadIdx.x;
         }
-        __syncthreads();
         // the pieces are dealt evenly: wave w takes [p_lo, p_hi).  (wave-uniform values are moved to scalar registers
         // explicitly: the loops below then run on the scalar unit and the lane broadcasts are v_readlane)
         P = __builtin_amdgcn_readfirstlane(P);
@@ -329,6 +340,12 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
         const uint32_t wv = __builtin_amdgcn_readfirstlane(wave);
         p_lo = (uint32_t)(((uint64_t)P * wv) / (TPB / 64));
         p_hi = (uint32_t)(((uint64_t)P * (wv + 1)) / (TPB / 64));
+    };
+    auto use_tables = [&](int buf) {
+        e_b = e_b0 + buf * EMAX;
+        e_e = e_e0 + buf * EMAX;
+        e_ps = e_ps0 + buf * EMAX;
+        piece_e = piece_e0 + buf * PMAX;
     };
     auto window = [&](uint32_t pw) {  // lane l looks up the entry of piece pw + l and keeps its range
         n_here = min(64u, p_hi - pw);
@@ -386,14 +403,12 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
             }
         }
     };
-    const bool pipelined = PIPELINE_TAIL && any_tail && n_chunks == 1;
-    if (pipelined) {  // prologue: tile 0's first pieces are requested before the loop
-        setup(0);
-        n_here = 0;
-        if (p_lo < p_hi) {
-            window(p_lo);
-            issue(0);
-        }
+    const bool pipelined = any_tail && n_chunks == 1;  // single-chunk rows: tile t + 1 is set up inside tile t
+    if (pipelined) {
+        setup_a(0, 0);
+        __syncthreads();
+        setup_b(0);
+        __syncthreads();
     }
     // In-place compaction of the provisional list by a threshold, staged through LDS in chunks (the tail accumulator
     // is idle — and all zero — between tiles; it is zeroed again afterwards).  Survivors of a chunk are appended to
@@ -451,12 +466,17 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
     int tile_no = 0;
     for (int32_t t0 = 0; t0 < U; t0 += TCOLS, ++tile_no) {
         if (pipelined) {
-            // this tile's first ILP pieces per wave were requested during the previous tile's select work
-            drain(true);
-            PH(4);  // LDS atomics (+ loads beyond the first ILP pieces)
-            __syncthreads();
+            use_tables(tile_no & 1);
+            drain(false);
+            PH(4);  // piece descriptors, loads, LDS atomics (this wave)
+            const bool more = t0 + TCOLS < U;
+            if (more) setup_a(tile_no + 1, (tile_no + 1) & 1);
+            __syncthreads();  // the tile's tail is complete — and the next tile's piece counts are visible
             PH(5);  // wait for the other waves
+            if (more) setup_b((tile_no + 1) & 1);  // (published by the barrier at the end of this tile)
+            else p_lo = p_hi = 0;
         } else if (any_tail) {
+            use_tables(0);
             for (int ch = 0; ch < n_chunks; ++ch) {
                 if (n_chunks > 1) {
                     __syncthreads();
@@ -465,26 +485,16 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
                     collect(ch);
                     __syncthreads();
                 }
-                setup(tile_no);
+                setup_a(tile_no, 0);
+                __syncthreads();
+                setup_b(0);
+                __syncthreads();
                 PH(2);  // ranges + prefix scan + piece table
                 drain(false);
                 PH(4);  // piece descriptors, loads, LDS atomics (this wave)
                 __syncthreads();
                 PH(5);  // wait for the other waves
             }
-        }
-        if (pipelined && t0 + TCOLS < U) {  // next tile's ranges, pieces and first loads: they fly during the select work
-            setup(tile_no + 1);
-            PH(2);
-            n_here = 0;
-            if (p_lo < p_hi) {
-                window(p_lo);
-                issue(0);
-            }
-            PH(3);
-        } else {
-            p_lo = p_hi = 0;
-            n_here = 0;
         }
         // the tile's panel entries (requested one tile ago) are needed only now; the next tile's are requested here,
         // so that they arrive behind the select work of this tile and the tail work of the next
@@ -648,7 +658,7 @@ template <class ST>
 static void launch_tail_select_t(const TailArgs& T, const ST* S, int64_t lds, int32_t n_rows, const int32_t* d_row_user,
                                  int32_t U, int32_t kk, float eps_opnd, float eps_rest, int32_t cap, int32_t* cand_idx, float* cand_approx,
                                  int32_t* cand_cnt, float* cand_eps, hipStream_t st) {
-    const size_t smem = (size_t)TCOLS * 4 + (size_t)NBINS * 4 + (size_t)EMAX * 16 + (size_t)PMAX * 2 + (TPB / 64 + 4) * 4;
+    const size_t smem = (size_t)TCOLS * 4 + (size_t)NBINS * 4 + (size_t)EMAX * 4 + 2 * ((size_t)EMAX * 12 + (size_t)PMAX * 2) + (2 * (TPB / 64) + 4) * 4;
     static bool attr_set = false;
     if (!attr_set) {
         KN_HIP(hipFuncSetAttribute((const void*)k_tail_select<ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
