@@ -434,9 +434,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_predict_knn_items(PredArgs A, in
     constexpr int CHUNK = 64;  // rows per workgroup
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ibw = (int)A.ib_words;
-    unsigned long long* bits = reinterpret_cast<unsigned long long*>(smem);              // [ibw]
-    uint32_t* rnk = reinterpret_cast<uint32_t*>(bits + ibw);                              // [ibw]
-    double* m_dev = reinterpret_cast<double*>(rnk + ((ibw + 1) & ~1));                    // [WAVES][CAP]
+    const int ibw2 = (ibw + 1) >> 1;  // pairs of bitmap words
+    // the rank prefixes are kept for every SECOND word only (the odd word adds the popcount of its even neighbour, which
+    // comes with the same 16-byte LDS read): 25 instead of 30 KB, which is what lets a third workgroup onto the CU
+    unsigned long long* bits = reinterpret_cast<unsigned long long*>(smem);              // [2 * ibw2]
+    uint32_t* rnk = reinterpret_cast<uint32_t*>(bits + 2 * ibw2);                         // [ibw2] raters before word 2 j
+    double* m_dev = reinterpret_cast<double*>(rnk + ((ibw2 + 1) & ~1));                   // [WAVES][CAP]
     double* m_sim = m_dev + WAVES * CAP;                                                  // [WAVES][CAP]
     uint32_t* m_t = reinterpret_cast<uint32_t*>(m_sim + WAVES * CAP);                     // [WAVES][CAP]
     __shared__ int64_t s_row[CHUNK];
@@ -479,9 +482,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_predict_knn_items(PredArgs A, in
         if (any) {
             const unsigned long long* gb = A.item_bits + (int64_t)item * ibw;
             const uint32_t* gr = A.item_rank + (int64_t)item * ibw;
-            for (int w = threadIdx.x; w < ibw; w += WAVES * 64) {
-                bits[w] = gb[w];
-                rnk[w] = gr[w];
+            for (int w = threadIdx.x; w < 2 * ibw2; w += WAVES * 64) {
+                bits[w] = w < ibw ? gb[w] : 0ull;
+                if ((w & 1) == 0) rnk[w >> 1] = gr[w];
             }
             __syncthreads();
             for (int rg = ra + wave * G; rg < rbn; rg += WAVES * G) {  // G rows of the run per wave and trip
@@ -517,10 +520,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_predict_knn_items(PredArgs A, in
                     for (int k = 0; k < TR; ++k) {  // probe the LDS bitmap, gather the matched ratings (file row, deviation)
                         const bool have = 64 * k + lane < cnts[g];
                         const uint32_t xi = have ? x[g][k] : 0u;
-                        const unsigned long long word = bits[xi >> 6];
+                        const uint32_t wi = xi >> 6;
+                        const ulonglong2 pair = *reinterpret_cast<const ulonglong2*>(bits + (wi & ~1u));
+                        const unsigned long long word = (wi & 1u) ? pair.y : pair.x;
                         const bool f = have && ((word >> (xi & 63u)) & 1ull);
                         fmask[g][k] = __ballot(f);
-                        const uint32_t q = f ? rbase[g] + rnk[xi >> 6] + (uint32_t)__popcll(word & ((1ull << (xi & 63u)) - 1ull)) : 0x0fffffffu;
+                        const uint32_t before = rnk[wi >> 1] + ((wi & 1u) ? (uint32_t)__popcll(pair.x) : 0u);
+                        const uint32_t q = f ? rbase[g] + before + (uint32_t)__popcll(word & ((1ull << (xi & 63u)) - 1ull)) : 0x0fffffffu;
                         mtv[g][k] = __builtin_amdgcn_raw_buffer_load_b32(r_t, (int)(q * 4u), 0, 0);
                         dv[g][k] = __builtin_amdgcn_raw_buffer_load_b64(r_dev, (int)(q * 8u), 0, 0);
                     }
@@ -664,7 +670,8 @@ void launch_predict(const Train& tr, const NeighborTable* nt, int predictor, int
             const unsigned blocks = (unsigned)ceil_div(n, 64);
 #define KN_LAUNCH_ITEMS(TRV, GV)                                                                                          \
     do {                                                                                                                  \
-        const size_t smem = (size_t)tr.ib_words * 8 + (size_t)((tr.ib_words + 1) & ~1) * 4 + (size_t)4 * (TRV * 64) * 20; \
+        const size_t ibw2 = (size_t)(tr.ib_words + 1) / 2;                                                                  \
+        const size_t smem = ibw2 * 16 + ((ibw2 + 1) & ~(size_t)1) * 4 + (size_t)4 * (TRV * 64) * 20;                        \
         KN_HIP(hipFuncSetAttribute((const void*)k_predict_knn_items<TRV, GV, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
         k_predict_knn_items<TRV, GV, 4><<<blocks, 256, smem, st>>>(A, n, d_du, d_di, d_ratings, d_order, d_pred, d_abs_err,  \
                                                                   d_owned, unknown_users_owned ? 1 : 0);                \
