@@ -372,13 +372,18 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
     // the entries come through a buffer descriptor: 32-bit offsets, and a lane outside its piece gets offset ~0, which
     // the range check answers with 0 — a word that adds nothing, so "w != 0" is the only predicate
     const __amdgpu_buffer_rsrc_t pack_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(T.it_pack), 0, T.pack_bytes, 0x00020000);
+    // (this loop is the kernel's VALU bottleneck — SQ counters: 78 % VALU issue utilisation — so instructions are
+    // counted: the lane's byte offset is precomputed, the piece's start comes as a scalar, and the LDS atomic takes the
+    // cell's byte address as is — the accumulator sits at LDS address 0)
+    const uint32_t lane4 = (uint32_t)lane << 2;
+    typedef __attribute__((address_space(3))) int32_t* lds_i32;
     auto issue = [&](uint32_t j0) {
 #pragma unroll
         for (int j = 0; j < ILP; ++j) {
             const int src = (int)min(j0 + j, 63u);  // wave-uniform
-            const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)d_q, src) + lane;
-            const uint32_t qend = (j0 + j < n_here) ? (uint32_t)__builtin_amdgcn_readlane((int)d_end, src) : 0u;
-            w[j] = __builtin_amdgcn_raw_buffer_load_b32(pack_rsrc, q < qend ? (int)(q << 2) : -1, 0, 0);
+            const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane((int)d_q, src);
+            const uint32_t len = (j0 + j < n_here) ? (uint32_t)__builtin_amdgcn_readlane((int)d_end, src) - q0 : 0u;  // scalar
+            w[j] = __builtin_amdgcn_raw_buffer_load_b32(pack_rsrc, (uint32_t)lane < len ? (int)((q0 << 2) + lane4) : -1, 0, 0);
         }
     };
     auto apply = [&](uint32_t j0) {
@@ -387,7 +392,8 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
             const float xf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d_x), (int)min(j0 + j, 63u)));
             if (w[j] != 0u) {
                 const int32_t qv = ((int32_t)(w[j] << 15)) >> 15;  // sign-extended low 17 bits
-                atomicAdd(&itile[w[j] >> 17], (int32_t)(xf * (float)qv));  // truncation: < 2^-24, inside row_eps' per-item term
+                // truncation: < 2^-24, inside row_eps' per-item term
+                __atomic_fetch_add((lds_i32)(uintptr_t)((w[j] >> 15) & 0x1fffcu), (int32_t)(xf * (float)qv), __ATOMIC_RELAXED);
             }
         }
     };
