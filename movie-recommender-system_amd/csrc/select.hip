@@ -40,6 +40,7 @@ __device__ unsigned long long g_phase[16];
 // __launch_bounds__(2 * TPB) caps the kernel at 128 VGPRs so that both workgroups fit.
 static constexpr int TPB = 512;
 static constexpr int NBINS = 1024;
+static constexpr int GCAP = SELECT_GCAP;  // provisional groups per row
 static constexpr int TCOLS = SELECT_TCOLS;  // columns of the row held in LDS at a time (64 KiB)
 static constexpr int CPT = TCOLS / TPB;  // columns per thread per tile (32 = 4 groups of 8)
 static constexpr int NG = CPT / 8;
@@ -161,7 +162,8 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
                                                      const int32_t* __restrict__ row_user, TailArgs T, int32_t U,
                                                      int32_t kk, float eps_opnd, float eps_rest, int32_t cap, int32_t* __restrict__ cand_idx,
                                                      float* __restrict__ cand_approx, int32_t* __restrict__ cand_cnt,
-                                                     float* __restrict__ cand_eps) {
+                                                     float* __restrict__ cand_eps, int32_t* __restrict__ grp_v0,
+                                                     float* __restrict__ grp_x) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int32_t* itile = reinterpret_cast<int32_t*>(smem);            // [TCOLS] tail accumulator, Q7.24, cell layout of it_pack
     uint32_t* hist = reinterpret_cast<uint32_t*>(itile + TCOLS);  // [NBINS]
@@ -193,6 +195,10 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
     const ST* row = S + (int64_t)r * ld;
     int32_t* out_idx = cand_idx + (int64_t)r * cap;
     float* out_apx = cand_approx + (int64_t)r * cap;
+    // provisional store of the row: whole GROUPS of 8 columns (first column + the 8 values) whose maximum reached the
+    // threshold known when their tile was processed; the columns are sorted out once, at the end
+    int32_t* g_v0 = grp_v0 + (int64_t)r * GCAP;
+    float4* g_x = reinterpret_cast<float4*>(grp_x + (int64_t)r * GCAP * 8);
     // this thread's CPT columns of a tile: group j covers columns t0 + 8 (tid + TPB j) .. + 7
     Raw8<ST> raw[NG];
 #pragma unroll
@@ -416,56 +422,18 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
         setup_b(0);
         __syncthreads();
     }
-    // In-place compaction of the provisional list by a threshold, staged through LDS in chunks (the tail accumulator
-    // is idle — and all zero — between tiles; it is zeroed again afterwards).  Survivors of a chunk are appended to
-    // the scratch with one LDS atomic per wave and copied back behind the survivors of the earlier chunks.
-    auto compact = [&](float thr) {
-        constexpr uint32_t CH = TCOLS / 2;
-        int32_t* sc_idx = itile;
-        float* sc_apx = reinterpret_cast<float*>(itile + CH);
-        uint32_t& s_cc = wtot[TPB / 64 + 3];
-        const uint32_t prov = s_count;
-        uint32_t kept = 0;
-        for (uint32_t base = 0; base < prov; base += CH) {
-            const uint32_t n_chunk = min(CH, prov - base);
-            if (threadIdx.x == 0) s_cc = 0;
-            __syncthreads();
-            for (uint32_t i0 = 0; i0 < n_chunk; i0 += TPB) {
-                const uint32_t i = i0 + threadIdx.x;
-                int32_t v = 0;
-                float x = -INFINITY;
-                if (i < n_chunk) {
-                    v = out_idx[base + i];
-                    x = out_apx[base + i];
-                }
-                const bool keep = x >= thr && i < n_chunk;
-                const unsigned long long km = __ballot(keep);
-                if (km) {
-                    uint32_t wbase = 0;
-                    if (lane == 0) wbase = atomicAdd(&s_cc, (uint32_t)__popcll(km));
-                    wbase = __builtin_amdgcn_readlane(wbase, 0);
-                    if (keep) {
-                        const uint32_t pos = wbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
-                        sc_idx[pos] = v;
-                        sc_apx[pos] = x;
-                    }
-                }
-            }
-            __syncthreads();
-            const uint32_t cc = s_cc;
-            for (uint32_t i = threadIdx.x; i < cc; i += TPB) {
-                out_idx[kept + i] = sc_idx[i];
-                out_apx[kept + i] = sc_apx[i];
-            }
-            kept += cc;
-            __syncthreads();
+    // histogram of every provisional value >= floor (values below the current threshold cannot be among the top k)
+    auto rebuild_hist = [&](float floor) {
+        for (int b2 = threadIdx.x; b2 < NBINS; b2 += TPB) hist[b2] = 0;
+        __syncthreads();
+        const uint32_t G = min(s_count, (uint32_t)GCAP);
+        for (uint32_t g = threadIdx.x; g < G; g += TPB) {
+            const float4 a = g_x[2 * g], b4 = g_x[2 * g + 1];
+            const float x8[8] = {a.x, a.y, a.z, a.w, b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (x8[i] >= floor && x8[i] > -INFINITY) atomicAdd(&hist[sim_bin(x8[i])], 1u);
         }
-        const uint32_t used = min(prov, CH);
-        for (uint32_t i = threadIdx.x; i < used; i += TPB) {
-            itile[i] = 0;
-            itile[CH + i] = 0;
-        }
-        if (threadIdx.x == 0) s_count = kept;
         __syncthreads();
     };
     PH(0);  // preamble: collect, clears
@@ -576,23 +544,17 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
             __syncthreads();
         }
         {
-            // One fused pass with the threshold known so far (it can only rise; a stale one just lets a few more
-            // provisional entries through): survivors enter the cumulative histogram and the provisional shortlist.
-            // Their slots come from ONE LDS atomic per wave (survivor bitmask per lane -> wave prefix sum), not one
-            // returning atomic per survivor: those round trips were the longest part of the tile.
+            // Emission with the threshold known so far (it can only rise; a stale one just lets more through): a group of
+            // 8 columns whose maximum qualifies is stored WHOLE (its 8 values, 32 contiguous bytes, + its first column).
+            // Sorting out the individual columns here — per-column masks, slots, histogram updates under divergent
+            // branches — cost a third of the kernel's VALU instructions (the kernel is VALU-bound); the few thousand
+            // stored values are sorted out once per row instead.  Slots: one LDS atomic per wave.
             const float thr = s_thr;
-            uint32_t m = 0;
+            uint32_t gmask = 0;
 #pragma unroll
-            for (int j = 0; j < NG; ++j) {
-                if (gm[j] >= thr) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const float x = sx[8 * j + i];
-                        if (x >= thr && x > -INFINITY) m |= 1u << (8 * j + i);
-                    }
-                }
-            }
-            const uint32_t cnt = __popc(m);
+            for (int j = 0; j < NG; ++j)
+                if (gm[j] >= thr && gm[j] > -INFINITY) gmask |= 1u << j;
+            const uint32_t cnt = __popc(gmask);
             const uint32_t incl = wave_incl_scan(cnt);
             const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
             if (total > 0) {
@@ -602,20 +564,12 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
                 const uint32_t first = base + incl - cnt;
 #pragma unroll
                 for (int j = 0; j < NG; ++j) {
-                    if ((m >> (8 * j)) & 0xffu) {
-                        const int32_t v0 = t0 + 8 * (threadIdx.x + TPB * j);
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const int bit = 8 * j + i;
-                            if (m & (1u << bit)) {
-                                const float x = sx[bit];
-                                atomicAdd(&hist[sim_bin(x)], 1u);
-                                const uint32_t pos = first + __popc(m & ((1u << bit) - 1u));
-                                if (pos < (uint32_t)cap) {
-                                    out_idx[pos] = v0 + i;
-                                    out_apx[pos] = x;
-                                }
-                            }
+                    if (gmask & (1u << j)) {
+                        const uint32_t pos = first + __popc(gmask & ((1u << j) - 1u));
+                        if (pos < (uint32_t)GCAP) {
+                            g_v0[pos] = t0 + 8 * (threadIdx.x + TPB * j);
+                            g_x[2 * pos] = make_float4(sx[8 * j], sx[8 * j + 1], sx[8 * j + 2], sx[8 * j + 3]);
+                            g_x[2 * pos + 1] = make_float4(sx[8 * j + 4], sx[8 * j + 5], sx[8 * j + 6], sx[8 * j + 7]);
                         }
                     }
                 }
@@ -624,27 +578,67 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
         PH(tile_no == 0 ? 7 : 8);  // histogram + emit
         __syncthreads();
         PH(9);
-        // Threshold refresh: once after the second tile (costs three barriers, tightens the rest), and whenever the
-        // provisional list has grown large (wide error bands, e.g. bf16 operands): then it is compacted as well, so
-        // that it only overflows — and the row falls back to the exact path — when the band itself is that crowded.
+        // Threshold refresh from the stored values: after the second tile (tightens the rest of the row) and whenever
+        // the store is filling up (wide error bands, e.g. bf16 operands)
         {
             const uint32_t prov = s_count;  // (block-uniform after the barrier)
-            const bool crowded = prov > (uint32_t)cap / 4 && prov <= (uint32_t)cap;
-            if (tile_no == 1 || crowded) block_threshold(hist, wtot, &s_thr, kk, eps);
-            if (crowded) compact(s_thr);
+            if ((tile_no == 1 || tile_no == 3 || tile_no == 6 || prov > (uint32_t)GCAP / 4) && prov <= (uint32_t)GCAP && t0 + TCOLS < U) {
+                rebuild_hist(s_thr);
+                block_threshold(hist, wtot, &s_thr, kk, eps);
+            }
         }
     }
 
-    // ---- compaction of the provisional list by the final threshold (in place) ------------------------
-    if (s_count > (uint32_t)cap) {  // provisional overflow: the exact fallback redoes this row
-        if (threadIdx.x == 0) cand_cnt[r] = (int32_t)min(s_count, (uint32_t)0x7fffffff);
+    // ---- the final threshold and the shortlist: every stored value >= T_r - 2 eps_r, with its column -------------------
+    if (s_count > (uint32_t)GCAP) {  // the store overflowed: the exact fallback redoes this row
+        if (threadIdx.x == 0) cand_cnt[r] = 0x7fffffff;
         return;
     }
-    block_threshold(hist, wtot, &s_thr, kk, eps);  // final: the whole row is in the histogram
-    compact(s_thr);
-    __syncthreads();
-    if (threadIdx.x == 0) cand_cnt[r] = (int32_t)s_count;
-    PH(10);  // final compaction
+    rebuild_hist(s_thr);
+    block_threshold(hist, wtot, &s_thr, kk, eps);  // final: every value that can matter is in the histogram
+    {
+        const float thr = s_thr;
+        const uint32_t G = s_count;
+        uint32_t& s_out = wtot[TPB / 64 + 3];
+        if (threadIdx.x == 0) s_out = 0;
+        __syncthreads();
+        for (uint32_t g0 = 0; g0 < G; g0 += TPB) {
+            const uint32_t g = g0 + threadIdx.x;
+            float x8[8];
+            int32_t v0 = 0;
+            uint32_t m = 0;
+            if (g < G) {
+                v0 = g_v0[g];
+                const float4 a = g_x[2 * g], b4 = g_x[2 * g + 1];
+                x8[0] = a.x; x8[1] = a.y; x8[2] = a.z; x8[3] = a.w; x8[4] = b4.x; x8[5] = b4.y; x8[6] = b4.z; x8[7] = b4.w;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (x8[i] >= thr && x8[i] > -INFINITY) m |= 1u << i;
+            }
+            const uint32_t cnt = __popc(m);
+            const uint32_t incl = wave_incl_scan(cnt);
+            const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+            if (total > 0) {
+                uint32_t base = 0;
+                if (lane == 63) base = atomicAdd(&s_out, total);
+                base = __builtin_amdgcn_readlane(base, 63);
+                uint32_t pos = base + incl - cnt;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (m & (1u << i)) {
+                        if (pos < (uint32_t)cap) {
+                            out_idx[pos] = v0 + i;
+                            out_apx[pos] = x8[i];
+                        }
+                        ++pos;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) cand_cnt[r] = (int32_t)min(s_out, (uint32_t)0x7fffffff);  // (> cap: overflow, exact fallback)
+    }
+    return;
 }
 
 #ifdef KNNCF_SELECT_PROFILE
@@ -663,14 +657,14 @@ void select_profile_dump() {
 template <class ST>
 static void launch_tail_select_t(const TailArgs& T, const ST* S, int64_t lds, int32_t n_rows, const int32_t* d_row_user,
                                  int32_t U, int32_t kk, float eps_opnd, float eps_rest, int32_t cap, int32_t* cand_idx, float* cand_approx,
-                                 int32_t* cand_cnt, float* cand_eps, hipStream_t st) {
+                                 int32_t* cand_cnt, float* cand_eps, int32_t* grp_v0, float* grp_x, hipStream_t st) {
     const size_t smem = (size_t)TCOLS * 4 + (size_t)NBINS * 4 + (size_t)EMAX * 4 + 2 * ((size_t)EMAX * 12 + (size_t)PMAX * 2) + (2 * (TPB / 64) + 4) * 4;
     static bool attr_set = false;
     if (!attr_set) {
         KN_HIP(hipFuncSetAttribute((const void*)k_tail_select<ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
-    k_tail_select<ST><<<n_rows, TPB, smem, st>>>(S, lds, n_rows, d_row_user, T, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps);
+    k_tail_select<ST><<<n_rows, TPB, smem, st>>>(S, lds, n_rows, d_row_user, T, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x);
     KN_HIP(hipGetLastError());
 #ifdef KNNCF_SELECT_PROFILE
     KN_HIP(hipStreamSynchronize(st));
@@ -680,7 +674,8 @@ static void launch_tail_select_t(const TailArgs& T, const ST* S, int64_t lds, in
 
 void launch_tail_select(const Train& tr, const int32_t* d_colmap, bool has_tail, const void* S, bool s_fp16, int64_t lds,
                         int32_t n_rows, const int32_t* d_row_user, int32_t k, float eps_opnd, float eps_rest, int32_t cap,
-                        int32_t* cand_idx, float* cand_approx, int32_t* cand_cnt, float* cand_eps, hipStream_t st) {
+                        int32_t* cand_idx, float* cand_approx, int32_t* cand_cnt, float* cand_eps, int32_t* grp_v0, float* grp_x,
+                        hipStream_t st) {
     if (n_rows <= 0) return;
     const int32_t U = tr.U;
     int32_t kk = k < U - 1 ? k : U - 1;
@@ -689,8 +684,8 @@ void launch_tail_select(const Train& tr, const int32_t* d_colmap, bool has_tail,
     static const bool debug_no_tail = getenv("KNNCF_DEBUG_NO_TAIL") != nullptr;  // timing experiments only: wrong results
     if (debug_no_tail) has_tail = false;
     TailArgs T{tr.u_ptr.p, tr.s_col.p, tr.s_pre.p, d_colmap, tr.i_ptr.p, tr.it_pack.p, (uint32_t)(tr.n * 4), tr.it_tile.p, tr.tile_stride, has_tail ? 1 : 0};
-    if (s_fp16) launch_tail_select_t(T, static_cast<const _Float16*>(S), lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, st);
-    else launch_tail_select_t(T, static_cast<const float*>(S), lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, st);
+    if (s_fp16) launch_tail_select_t(T, static_cast<const _Float16*>(S), lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, st);
+    else launch_tail_select_t(T, static_cast<const float*>(S), lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, st);
 }
 
 }  // namespace knncf
