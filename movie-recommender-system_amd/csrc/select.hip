@@ -19,6 +19,8 @@
 // the exact top-k; rerank.hip decides.  HBM-bound: S is read exactly once and never written back; the
 // tail's per-pair products never touch HBM atomics.
 #include <math.h>
+
+#include <type_traits>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -381,37 +383,43 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
     // (this loop is the kernel's VALU bottleneck — SQ counters: 78 % VALU issue utilisation — so instructions are
     // counted: the lane's byte offset is precomputed, the piece's start comes as a scalar, and the LDS atomic takes the
     // cell's byte address as is — the accumulator sits at LDS address 0)
-    const uint32_t lane4 = (uint32_t)lane << 2;
     typedef __attribute__((address_space(3))) int32_t* lds_i32;
-    auto issue = [&](uint32_t j0) {
+    // a lane without an entry (the tail of a piece) adds 0 to a scratch cell of its own instead of being branched around:
+    // besides VALU, the loop is bound by the CU's single scalar unit (SQ counters), and a branch costs three scalar ops
+    const uint32_t dummy_addr = (uint32_t)(reinterpret_cast<char*>(wtot2 + TPB / 64) - smem) + ((uint32_t)lane << 2);
+    // FULL: all ILP pieces exist (no per-piece bound check); otherwise pieces past n_here get an empty range
+    auto issue = [&](uint32_t j0, auto full) {
+        constexpr bool FULL = decltype(full)::value;
 #pragma unroll
         for (int j = 0; j < ILP; ++j) {
-            const int src = (int)min(j0 + j, 63u);  // wave-uniform
+            const int src = FULL ? (int)(j0 + j) : (int)min(j0 + j, 63u);  // wave-uniform
             const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane((int)d_q, src);
-            const uint32_t len = (j0 + j < n_here) ? (uint32_t)__builtin_amdgcn_readlane((int)d_end, src) - q0 : 0u;  // scalar
-            w[j] = __builtin_amdgcn_raw_buffer_load_b32(pack_rsrc, (uint32_t)lane < len ? (int)((q0 << 2) + lane4) : -1, 0, 0);
+            const uint32_t len = (FULL || j0 + j < n_here) ? (uint32_t)__builtin_amdgcn_readlane((int)d_end, src) - q0 : 0u;  // scalar
+            w[j] = __builtin_amdgcn_raw_buffer_load_b32(pack_rsrc, (uint32_t)lane < len ? (int)((q0 + lane) << 2) : -1, 0, 0);
         }
     };
-    auto apply = [&](uint32_t j0) {
+    auto apply = [&](uint32_t j0, auto full) {
+        constexpr bool FULL = decltype(full)::value;
 #pragma unroll
         for (int j = 0; j < ILP; ++j) {
-            const float xf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d_x), (int)min(j0 + j, 63u)));
-            if (w[j] != 0u) {
-                const int32_t qv = ((int32_t)(w[j] << 15)) >> 15;  // sign-extended low 17 bits
-                // truncation: < 2^-24, inside row_eps' per-item term
-                __atomic_fetch_add((lds_i32)(uintptr_t)((w[j] >> 15) & 0x1fffcu), (int32_t)(xf * (float)qv), __ATOMIC_RELAXED);
-            }
+            const float xf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d_x), FULL ? (int)(j0 + j) : (int)min(j0 + j, 63u)));
+            const int32_t qv = ((int32_t)(w[j] << 15)) >> 15;  // sign-extended low 17 bits (0 for a lane without an entry)
+            const uint32_t addr = w[j] != 0u ? ((w[j] >> 15) & 0x1fffcu) : dummy_addr;
+            // truncation: < 2^-24, inside row_eps' per-item term
+            __atomic_fetch_add((lds_i32)(uintptr_t)addr, (int32_t)(xf * (float)qv), __ATOMIC_RELAXED);
         }
     };
-    // everything after the first ILP pieces of the wave's first window (those are issued ahead, see below)
-    auto drain = [&](bool first_issued) {
-        bool skip = first_issued;
+    auto drain = [&](bool) {
         for (uint32_t pw = p_lo; pw < p_hi; pw += 64) {
-            if (!skip) window(pw);
-            for (uint32_t j0 = 0; j0 < n_here; j0 += ILP) {
-                if (!skip) issue(j0);
-                skip = false;
-                apply(j0);
+            window(pw);
+            uint32_t j0 = 0;
+            for (; j0 + ILP <= n_here; j0 += ILP) {
+                issue(j0, std::true_type{});
+                apply(j0, std::true_type{});
+            }
+            if (j0 < n_here) {
+                issue(j0, std::false_type{});
+                apply(j0, std::false_type{});
             }
         }
     };
@@ -658,7 +666,7 @@ template <class ST>
 static void launch_tail_select_t(const TailArgs& T, const ST* S, int64_t lds, int32_t n_rows, const int32_t* d_row_user,
                                  int32_t U, int32_t kk, float eps_opnd, float eps_rest, int32_t cap, int32_t* cand_idx, float* cand_approx,
                                  int32_t* cand_cnt, float* cand_eps, int32_t* grp_v0, float* grp_x, hipStream_t st) {
-    const size_t smem = (size_t)TCOLS * 4 + (size_t)NBINS * 4 + (size_t)EMAX * 4 + 2 * ((size_t)EMAX * 12 + (size_t)PMAX * 2) + (2 * (TPB / 64) + 4) * 4;
+    const size_t smem = (size_t)TCOLS * 4 + (size_t)NBINS * 4 + (size_t)EMAX * 4 + 2 * ((size_t)EMAX * 12 + (size_t)PMAX * 2) + (2 * (TPB / 64) + 4 + 64) * 4;  // + 64 scratch cells
     static bool attr_set = false;
     if (!attr_set) {
         KN_HIP(hipFuncSetAttribute((const void*)k_tail_select<ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
