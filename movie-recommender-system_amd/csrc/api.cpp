@@ -311,6 +311,7 @@ void build_neighbors(knncf_handle* h, int32_t count) {
     h->sel.cand_approx.ensure((size_t)R * cap);
     h->sel.cand_cnt.ensure(R);
     h->sel.cand_eps.ensure(R);
+    h->sel.row_entries.ensure(R);
     h->sel.grp_v0.ensure((size_t)R * SELECT_GCAP);
     h->sel.grp_x.ensure((size_t)R * SELECT_GCAP * 8);
     h->sel.stats.ensure(4);
@@ -364,7 +365,7 @@ void build_neighbors(knncf_handle* h, int32_t count) {
         {
             Stage s(h, &h->tm.rerank_ms, sc);
             launch_rerank(tr, nt, rows, d_rows, cap, h->sel.cand_idx.p, h->sel.cand_approx.p, h->sel.cand_cnt.p, h->sel.cand_eps.p,
-                          h->sel.stats.p, verify, sc);
+                          h->sel.stats.p, h->sel.row_entries.p, verify, sc);
         }
         if (!overlap) KN_HIP(hipEventRecord(h->ev_consumed[slot], sc));
         KN_HIP(hipMemcpyAsync(h->pinned_cnt + rb, h->sel.cand_cnt.p, rows * sizeof(int32_t), hipMemcpyDeviceToHost, sc));

@@ -132,6 +132,7 @@ struct SelectScratch {
     DArr<int32_t> grp_v0;     // [rows * SELECT_GCAP] provisional groups: first column
     DArr<float> grp_x;        // [rows * SELECT_GCAP * 8] their 8 values
     DArr<double> stats;       // [4]: max bound violation, ...
+    DArr<uint32_t> row_entries;  // [rows] ratings of the row's shortlisted candidates (re-rank traffic accounting)
     DArr<double> row_exact;   // fallback: [U] exact similarities of one row
     DArr<uint64_t> fb_keys_a, fb_keys_b;
     DArr<uint32_t> fb_vals_a, fb_vals_b;
@@ -146,7 +147,8 @@ void launch_tail_select(const Train& tr, const int32_t* d_colmap, bool has_tail,
 // exact fp64 similarities of the shortlists in reference order, stable top-k
 void launch_rerank(const Train& tr, NeighborTable& nt, int32_t n_rows, const int32_t* d_row_user,
                    int32_t cap, const int32_t* cand_idx, const float* cand_approx,
-                   const int32_t* cand_cnt, const float* cand_eps, double* d_stats, bool verify, hipStream_t st);
+                   const int32_t* cand_cnt, const float* cand_eps, double* d_stats, uint32_t* d_row_entries, bool verify,
+                   hipStream_t st);
 // exact similarities of one user against everyone (fallback + scalar queries)
 void launch_exact_row(const Train& tr, const NeighborTable& nt, int32_t user, int64_t user_seq,
                       double* d_out, hipStream_t st);

@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(TPB) k_rerank(Rows R, const int64_t* __restric
                                                 const int32_t* __restrict__ cand_cnt, int32_t kk, int32_t kcap,
                                                 int32_t* __restrict__ nbr_idx, double* __restrict__ nbr_sim,
                                                 int32_t* __restrict__ nbr_cnt, const float* __restrict__ cand_eps,
-                                                double* __restrict__ stats, int32_t words) {
+                                                double* __restrict__ stats, uint32_t* __restrict__ row_entries_out, int32_t words) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t part[TPB];
     double* ssim = reinterpret_cast<double*>(smem);            // [TILE]
@@ -301,10 +301,15 @@ __global__ void __launch_bounds__(TPB) k_rerank(Rows R, const int64_t* __restric
     int32_t* sidx = reinterpret_cast<int32_t*>(wbuf + (TPB / 64) * WBUF);  // [TILE]
     u32x2* bp = reinterpret_cast<u32x2*>(sidx + TILE);         // [words] (bitmap word of u's items, items of u before it)
     uint32_t* wmeta = reinterpret_cast<uint32_t*>(bp + words);  // [TPB / 64][WMETA]
+    __shared__ unsigned long long s_entries;
     const int32_t r = blockIdx.x;
     if (r >= n_rows) return;
     const int32_t cnt = cand_cnt[r];
-    if (cnt > cap) return;  // overflow: the exact fallback redoes this row
+    if (cnt > cap) {  // overflow: the exact fallback redoes this row
+        if (threadIdx.x == 0) row_entries_out[r] = 0;
+        return;
+    }
+    if (threadIdx.x == 0) s_entries = 0;
 #ifdef KNNCF_RERANK_PROFILE
     long long ph_t = clock64();
 #endif
@@ -410,8 +415,12 @@ __global__ void __launch_bounds__(TPB) k_rerank(Rows R, const int64_t* __restric
         pos += take;
         RPH(3);  // sort
     } while (pos < cnt);
+    // (one global atomic per wave on a single address throttled the whole kernel: -4.8 ms of 24.5 without it.  The
+    // counts go to a per-row array instead and are summed by k_sum_row_entries.)
     for (int o = 32; o > 0; o >>= 1) row_entries += __shfl_xor(row_entries, o);
-    if (lane == 0 && row_entries > 0) atomicAdd(reinterpret_cast<unsigned long long*>(stats) + 1, (unsigned long long)row_entries);
+    if (lane == 0) atomicAdd(&s_entries, (unsigned long long)row_entries);  // LDS
+    __syncthreads();
+    if (threadIdx.x == 0) row_entries_out[r] = (uint32_t)min(s_entries, 0xffffffffull);
     if (cand_approx) {
         // max over the grid of (|approx - exact| - eps); must stay <= 0
         for (int o = 32; o > 0; o >>= 1) worst = fmax(worst, __shfl_xor(worst, o));
@@ -444,10 +453,23 @@ static void rerank_profile_dump() {
 }
 #endif
 
+// stats[1] += sum of the per-row candidate-entry counts (the kernel's algorithmic traffic / 12 B): one atomic per block
+__global__ void __launch_bounds__(1024) k_sum_row_entries(int32_t n_rows, const uint32_t* __restrict__ row_entries, unsigned long long* __restrict__ total) {
+    __shared__ unsigned long long part;
+    if (threadIdx.x == 0) part = 0;
+    __syncthreads();
+    const int32_t r = blockIdx.x * 1024 + threadIdx.x;
+    unsigned long long v = r < n_rows ? row_entries[r] : 0ull;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&part, v);
+    __syncthreads();
+    if (threadIdx.x == 0 && part) atomicAdd(total, part);
+}
+
 template <int TILE>
 static void launch_rerank_tile(const Rows& R, const Train& tr, NeighborTable& nt, int32_t n_rows, const int32_t* d_row_user,
                                int32_t cap, const int32_t* cand_idx, const float* cand_approx, const int32_t* cand_cnt,
-                               const float* cand_eps, double* d_stats, hipStream_t st) {
+                               const float* cand_eps, double* d_stats, uint32_t* d_row_entries, hipStream_t st) {
     const int32_t words = (int32_t)ceil_div(tr.I, 32);
     const size_t smem = (size_t)TILE * 8 + (size_t)UPRE_LDS * 8 + (size_t)(TPB / 64) * WBUF * 8 + (size_t)TILE * 4 +
                         (size_t)words * 8 + (size_t)(TPB / 64) * WMETA * 4;
@@ -458,7 +480,8 @@ static void launch_rerank_tile(const Rows& R, const Train& tr, NeighborTable& nt
         attr = smem;
     }
     k_rerank<TILE><<<n_rows, TPB, smem, st>>>(R, nt.seq.p, n_rows, d_row_user, cap, cand_idx, cand_approx, cand_cnt, nt.kcap,
-                                              nt.kcap, nt.idx.p, nt.sim.p, nt.cnt.p, cand_eps, d_stats, words);
+                                              nt.kcap, nt.idx.p, nt.sim.p, nt.cnt.p, cand_eps, d_stats, d_row_entries, words);
+    k_sum_row_entries<<<(unsigned)ceil_div(n_rows, 1024), 1024, 0, st>>>(n_rows, d_row_entries, reinterpret_cast<unsigned long long*>(d_stats) + 1);
     KN_HIP(hipGetLastError());
 #ifdef KNNCF_RERANK_PROFILE
     KN_HIP(hipStreamSynchronize(st));
@@ -468,13 +491,13 @@ static void launch_rerank_tile(const Rows& R, const Train& tr, NeighborTable& nt
 
 void launch_rerank(const Train& tr, NeighborTable& nt, int32_t n_rows, const int32_t* d_row_user, int32_t cap,
                    const int32_t* cand_idx, const float* cand_approx, const int32_t* cand_cnt, const float* cand_eps,
-                   double* d_stats, bool verify, hipStream_t st) {
+                   double* d_stats, uint32_t* d_row_entries, bool verify, hipStream_t st) {
     if (n_rows <= 0) return;
     KN_REQUIRE(nt.kcap <= 1024, KNNCF_E_UNSUPPORTED, "k > 1024 is not supported by the re-rank kernel yet");
     Rows R{tr.u_ptr.p, tr.s_col.p, tr.s_t.p, tr.s_pre.p, (uint32_t)(tr.n * 4), (uint32_t)(tr.n * 8)};
     const float* apx = verify ? cand_approx : nullptr;
-    if (nt.kcap <= 512) launch_rerank_tile<1024>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, st);
-    else launch_rerank_tile<2048>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, st);
+    if (nt.kcap <= 512) launch_rerank_tile<1024>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
+    else launch_rerank_tile<2048>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
 }
 
 // exact similarities of one user against everyone (out[user] = -inf): the fallback for rows whose
