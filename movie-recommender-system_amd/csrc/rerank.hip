@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(TPB) k_rerank(Rows R, const int64_t* __restric
                                                 int32_t* __restrict__ nbr_cnt, const float* __restrict__ cand_eps,
                                                 double* __restrict__ stats, uint32_t* __restrict__ row_entries_out, int32_t words) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ uint32_t part[TPB];
+    __shared__ uint32_t part[TPB / 64];
     double* ssim = reinterpret_cast<double*>(smem);            // [TILE]
     double* upre = ssim + TILE;                                // [UPRE_LDS]
     double* wbuf = upre + UPRE_LDS;                            // [4][WBUF]
@@ -331,15 +331,13 @@ __global__ void __launch_bounds__(TPB) k_rerank(Rows R, const int64_t* __restric
     const int32_t w0 = min(words, (int32_t)threadIdx.x * per), w1 = min(words, w0 + per);
     uint32_t mine = 0;
     for (int32_t w = w0; w < w1; ++w) mine += __popc(bp[w].x);
-    part[threadIdx.x] = mine;
+    // exclusive prefix over the threads: DPP scan inside the wave, the waves' totals through LDS (one barrier)
+    const uint32_t incl_w = wave_incl_scan(mine);
+    if (lane == 63) part[wave] = incl_w;
     __syncthreads();
-    for (int o = 1; o < TPB; o <<= 1) {  // inclusive prefix scan
-        uint32_t add = (threadIdx.x >= (unsigned)o) ? part[threadIdx.x - o] : 0;
-        __syncthreads();
-        part[threadIdx.x] += add;
-        __syncthreads();
-    }
-    uint32_t run = part[threadIdx.x] - mine;
+    uint32_t before = 0;
+    for (int w = 0; w < wave; ++w) before += part[w];
+    uint32_t run = before + incl_w - mine;
     for (int32_t w = w0; w < w1; ++w) {
         bp[w].y = run;
         run += __popc(bp[w].x);
