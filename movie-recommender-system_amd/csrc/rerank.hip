@@ -185,12 +185,9 @@ typedef __attribute__((address_space(3))) u32x2* lds_u32x2;
 
 template <class PreP>
 __device__ __forceinline__ double wave_sims(const Rows& R, lds_cu32x2 bp, PreP upre, int32_t nu, lds_f64 wb, lds_u32 meta,
-                                            int32_t my_v, int n_c, int lane) {
+                                            uint32_t my_b, uint32_t my_len, int n_c, int lane) {
     lds_u32x2 cpair = (lds_u32x2)meta;  // [64] (end of candidate j in the stream, entry of stream position 0 of j)
     lds_u32 cofs = meta + 128;          // [65] first product of candidate j in the product buffer
-    const bool have = lane < n_c;
-    const uint32_t my_b = have ? (uint32_t)R.u_ptr[my_v] : 0u;  // n < 2^29 (checked at fit)
-    const uint32_t my_len = have ? (uint32_t)R.u_ptr[my_v + 1] - my_b : 0u;
     const uint32_t incl = wave_incl_scan(my_len);
     const uint32_t E = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     {
@@ -318,6 +315,23 @@ __global__ void __launch_bounds__(TPB) k_rerank(Rows R, const int64_t* __restric
     const int64_t ub = R.u_ptr[u];
     const int32_t nu = (int32_t)(R.u_ptr[u + 1] - ub);
     const bool pre_lds = nu <= UPRE_LDS;
+    // the wave's candidates of the first trip and their row extents: a chain of three dependent loads (count -> ids ->
+    // extents) that is requested here so that it runs behind the set-up of u's bitmap instead of in front of the stream
+    const int32_t* my_cand = cand_idx + (int64_t)r * cap;
+    int32_t v_first = 0;
+    uint32_t b_first = 0, len_first = 0;
+    {
+        const int32_t take0 = min(TILE, cnt);
+        const int32_t in_trip = min(TPB, take0);
+        const int32_t per = (in_trip + TPB / 64 - 1) / (TPB / 64);
+        const int32_t c0 = wave * per;
+        const int n_c = max(0, min(per, in_trip - c0));
+        if (lane < n_c) {
+            v_first = my_cand[c0 + lane];
+            b_first = (uint32_t)R.u_ptr[v_first];  // n < 2^29 (checked at fit)
+            len_first = (uint32_t)R.u_ptr[v_first + 1] - b_first;
+        }
+    }
     // u's items as a bitmap + exclusive prefix popcounts
     for (int32_t w = threadIdx.x; w < words; w += TPB) bp[w] = u32x2{0u, 0u};
     __syncthreads();
@@ -344,7 +358,6 @@ __global__ void __launch_bounds__(TPB) k_rerank(Rows R, const int64_t* __restric
     }
     const int64_t seq_u = seq[u];
     const float eps = cand_eps[r];  // the band select.hip used for this row (KNNCF_FLAG_VERIFY_BOUND)
-    const int32_t* my_cand = cand_idx + (int64_t)r * cap;
     lds_f64 wb = (lds_f64)(wbuf + wave * WBUF);
     lds_u32 meta = (lds_u32)(wmeta + wave * WMETA);
     double worst = -1.0;
@@ -363,15 +376,20 @@ __global__ void __launch_bounds__(TPB) k_rerank(Rows R, const int64_t* __restric
             const int32_t c0 = t0 + wave * per;
             const int n_c = max(0, min(per, t0 + in_trip - c0));
             if (n_c == 0) continue;
-            const int32_t v = (lane < n_c) ? my_cand[pos + c0 + lane] : 0;
+            int32_t v = v_first;
+            uint32_t b_v = b_first, len_v = len_first;
+            if (pos + t0 > 0) {  // (later trips / rounds: rare for k <= 512)
+                v = (lane < n_c) ? my_cand[pos + c0 + lane] : 0;
+                b_v = (lane < n_c) ? (uint32_t)R.u_ptr[v] : 0u;
+                len_v = (lane < n_c) ? (uint32_t)R.u_ptr[v + 1] - b_v : 0u;
+            }
             double s;
             // Set1..Set4 iterate in file order and the memo history matters (N2, N6): scalar path
-            const int64_t len_v = (lane < n_c) ? (R.u_ptr[v + 1] - R.u_ptr[v]) : 0;
             row_entries += len_v;  // algorithmic traffic of this kernel: the candidates' rows (12 B per entry)
             const bool small_v = (lane < n_c) && (len_v <= 4);
             if (nu > 4 && !__any(small_v)) {
-                s = pre_lds ? wave_sims(R, (lds_cu32x2)bp, (lds_cf64)upre, nu, wb, meta, v, n_c, lane)
-                            : wave_sims(R, (lds_cu32x2)bp, R.s_pre + ub, nu, wb, meta, v, n_c, lane);
+                s = pre_lds ? wave_sims(R, (lds_cu32x2)bp, (lds_cf64)upre, nu, wb, meta, b_v, len_v, n_c, lane)
+                            : wave_sims(R, (lds_cu32x2)bp, R.s_pre + ub, nu, wb, meta, b_v, len_v, n_c, lane);
             } else {
                 s = (lane < n_c) ? pair_sim(R, u, v, seq_u, seq[v]) : 0.0;
             }
