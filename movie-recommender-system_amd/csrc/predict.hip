@@ -545,29 +545,41 @@ __global__ void __launch_bounds__(WAVES * 64) k_predict_knn_items(PredArgs A, in
                         }
                         total += __popcll(hit);
                     }
+                    if (total == 0) continue;  // no neighbour rated the item: the prediction is the user's mean (preset)
                     // order the matches by training file row (the order of ratedI(i) :508-517): rank by counting
-                    for (int32_t c = total + lane; c < ((total + 3) & ~3); c += 64) mt[c] = 0xffffffffu;
-                    wave_sync();
-                    uint32_t key[TR], rank[TR];
-                    double kd[TR], ks[TR];
-#pragma unroll
-                    for (int k = 0; k < TR; ++k) {
-                        const int32_t slot = 64 * k + lane;
-                        rank[k] = 0; key[k] = 0; kd[k] = 0.0; ks[k] = 0.0;
-                        if (slot < total) { key[k] = mt[slot]; kd[k] = md[slot]; ks[k] = ms[slot]; }
-                    }
-                    const int nslot = (total + 63) >> 6;
-                    const uint4* keys4 = reinterpret_cast<const uint4*>(mt);
-                    for (int32_t c = 0; c < ((total + 3) >> 2); ++c) {
-                        const uint4 kq = keys4[c];
-#pragma unroll
+                    if (total <= 64) {
+                        // the common case (~14 matches): one match per lane, the keys travel by v_readlane
+                        wave_sync();
+                        uint32_t key = 0xffffffffu, rk = 0;
+                        double kd = 0.0, ks = 0.0;
+                        if (lane < total) { key = mt[lane]; kd = md[lane]; ks = ms[lane]; }
+                        for (int32_t c = 0; c < total; ++c) rk += (uint32_t)((uint32_t)__builtin_amdgcn_readlane((int)key, c) < key);
+                        if (lane < total) { md[rk] = kd; ms[rk] = ks; }
+                        wave_sync();
+                    } else {
+                        for (int32_t c = total + lane; c < ((total + 3) & ~3); c += 64) mt[c] = 0xffffffffu;
+                        wave_sync();
+                        uint32_t key[TR], rank[TR];
+                        double kd[TR], ks[TR];
+    #pragma unroll
+                        for (int k = 0; k < TR; ++k) {
+                            const int32_t slot = 64 * k + lane;
+                            rank[k] = 0; key[k] = 0; kd[k] = 0.0; ks[k] = 0.0;
+                            if (slot < total) { key[k] = mt[slot]; kd[k] = md[slot]; ks[k] = ms[slot]; }
+                        }
+                        const int nslot = (total + 63) >> 6;
+                        const uint4* keys4 = reinterpret_cast<const uint4*>(mt);
+                        for (int32_t c = 0; c < ((total + 3) >> 2); ++c) {
+                            const uint4 kq = keys4[c];
+    #pragma unroll
+                            for (int k = 0; k < TR; ++k)
+                                if (k < nslot) rank[k] += (uint32_t)(kq.x < key[k]) + (uint32_t)(kq.y < key[k]) + (uint32_t)(kq.z < key[k]) + (uint32_t)(kq.w < key[k]);
+                        }
+    #pragma unroll
                         for (int k = 0; k < TR; ++k)
-                            if (k < nslot) rank[k] += (uint32_t)(kq.x < key[k]) + (uint32_t)(kq.y < key[k]) + (uint32_t)(kq.z < key[k]) + (uint32_t)(kq.w < key[k]);
+                            if (64 * k + lane < total) { md[rank[k]] = kd[k]; ms[rank[k]] = ks[k]; }
+                        wave_sync();
                     }
-#pragma unroll
-                    for (int k = 0; k < TR; ++k)
-                        if (64 * k + lane < total) { md[rank[k]] = kd[k]; ms[rank[k]] = ks[k]; }
-                    wave_sync();
                     double num = 0.0, den = 0.0;
                     for (int32_t c = 0; c < total; ++c) {  // every lane folds the same sequence (LDS broadcast)
                         const double sc = ms[c];
