@@ -106,6 +106,28 @@ __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// LDS plan of the persistent kernel: [PAD][slot 0][slot 1][PAD]; a slot = one k-tile of A and of B.  The epilogue image
+// of a tile reuses the slot that was consumed last (the other one already receives the next tile's first k-tile) and
+// may spill into the PAD next to it.
+template <class OT, int WM, int WAVES_M, int TB>
+struct EpiGeom {
+    static constexpr int ESZ = (int)sizeof(OT);
+    static constexpr int IPP = ESZ == 2 ? WM : (WM >= 2 ? WM / 2 : 1);   // 32-row MFMA blocks of a wave per pass
+    static constexpr int PASS_ROWS = IPP * 32;
+    static constexpr int PASSES = WAVES_M * (WM / IPP);
+    static constexpr int RS = TB * ESZ + 16;                             // LDS row stride of the image
+    static constexpr int IMAGE = PASS_ROWS * RS;
+    static constexpr int STAGE = TileGeom<TB>::STAGE_BYTES;
+    static constexpr int PAD = IMAGE > STAGE ? ((IMAGE - STAGE + 1023) / 1024) * 1024 : 0;
+    static constexpr int SMEM = 2 * STAGE + 2 * PAD;
+};
+
+// Persistent: one workgroup per CU slot walks its share of the tile sequence.  The k-tiles of consecutive tiles form
+// ONE stream through the 2-slot ring, so the first k-tile of the next tile loads under the last MFMA step and the
+// epilogue of this one, and the epilogue's global stores drain under the next tile's first MFMA step (measured with
+// the stores / the MFMAs ablated: the per-tile kernel spent 10 of its 23 ms waiting for its own stores at K = 256).
+// (Splitting the waves into loaders and storers, so that no counted load wait stands behind a store, was slower:
+// 9.6 vs 6.9 ms per launch — four waves do not issue the LDS-DMA stream fast enough.)
 template <bool F16, class OT, int WM, int WN, int WAVES_M, int WAVES_N>
 __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64)
 k_gemm_nt_bf16(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, OT* __restrict__ C, int tiles_m,
@@ -113,125 +135,168 @@ k_gemm_nt_bf16(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, OT* _
     constexpr int WAVES = WAVES_M * WAVES_N;
     constexpr int TBM = WAVES_M * WM * 32, TBN = WAVES_N * WN * 32;
     static_assert(TBM == TBN, "square block tiles: both operand tiles share one staging routine");
+    typedef EpiGeom<OT, WM, WAVES_M, TBM> EG;
     constexpr int TILE_BYTES = TileGeom<TBM>::TILE_BYTES, STAGE_BYTES = TileGeom<TBM>::STAGE_BYTES;
     constexpr int LOADS_PER_STAGE = 2 * (TBM / 8 / WAVES);  // LDS-DMA instructions per wave per stage
-    extern __shared__ __attribute__((aligned(1024))) char lds[];  // 2 stages x (A tile + B tile)
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    char* const ring = lds + EG::PAD;
 
-    // XCD-aware tile order: blocks that share an XCD (equal blockIdx % 8, observed round-robin
-    // placement; speed only) walk neighbouring tiles so that A/B panels are reused out of that
-    // XCD's L2.  Bijective remap for any grid size.
+    // XCD-aware tile order: blocks that share an XCD (equal blockIdx % 8, observed round-robin placement; speed
+    // only) own one contiguous range of the tile sequence and walk it side by side, so that A/B panels are reused
+    // out of that XCD's L2.  Every tile is visited exactly once for any grid size.
     const int nwg = tiles_m * tiles_n;
-    const int orig = blockIdx.x;
-    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    // grouped ordering: 8 tile-rows at a time, column-major inside a group
-    const int GROUP = 8;
-    const int group_sz = GROUP * tiles_n;
-    const int gid = wg / group_sz;
-    const int first_m = gid * GROUP;
-    const int gm = min(GROUP, tiles_m - first_m);
-    const int tm = first_m + (wg % group_sz) % gm;
-    const int tn = (wg % group_sz) / gm;
+    const int xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
+    const int xcd_first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int xcd_end = xcd_first + (xcd < r ? q + 1 : q);
+    const int stride = ((int)gridDim.x - xcd + 7) >> 3;        // blocks of this XCD
+    int t = xcd_first + ((int)blockIdx.x >> 3);
+    if (t >= xcd_end) return;
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int wr = wave / WAVES_N, wc = wave % WAVES_N;
-
-    const bf16_t* Ag = A + (int64_t)tm * TBM * lda;
-    const bf16_t* Bg = B + (int64_t)tn * TBN * ldb;
-
-    f32x16 acc[WM][WN];
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    stage_tile<TBM, WAVES>(Ag, lda, lds, wave, lane);
-    stage_tile<TBN, WAVES>(Bg, ldb, lds + TILE_BYTES, wave, lane);
-
     const int frow = lane & 31;  // fragment row inside a 32-row MFMA tile
     const int fhalf = lane >> 5; // which 8-wide k half of the 16-wide k-step
 
-    for (int kt = 0; kt < k_tiles; ++kt) {
-        char* cur = lds + (kt & 1) * STAGE_BYTES;
-        if (kt + 1 < k_tiles) {
-            char* nxt = lds + ((kt + 1) & 1) * STAGE_BYTES;
-            stage_tile<TBM, WAVES>(Ag + (int64_t)(kt + 1) * BK, lda, nxt, wave, lane);
-            stage_tile<TBN, WAVES>(Bg + (int64_t)(kt + 1) * BK, ldb, nxt + TILE_BYTES, wave, lane);
-            // tile kt landed; tile kt+1 (LOADS_PER_STAGE DMAs of this wave) stays in flight across the barrier
-            static_assert(LOADS_PER_STAGE == 8 || LOADS_PER_STAGE == 16, "the counted vmcnt below assumes 8 or 16 LDS-DMA instructions per wave per stage");
-            if (LOADS_PER_STAGE == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 a[WM];
-#pragma unroll
-            for (int i = 0; i < WM; ++i) a[i] = read_frag(cur, wr * (WM * 32) + i * 32 + frow, ks * 2 + fhalf);
-            bf16x8 b[WN];
-#pragma unroll
-            for (int j = 0; j < WN; ++j) b[j] = read_frag(cur + TILE_BYTES, wc * (WN * 32) + j * 32 + frow, ks * 2 + fhalf);
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int j = 0; j < WN; ++j)
-                    // operands swapped (D' = B A^T): a lane then holds ONE row of S and groups of 4 consecutive columns
-                    acc[i][j] = mfma<F16>(b[j], a[i], acc[i][j]);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // everyone is done reading `cur` before it is restaged
-        asm volatile("" ::: "memory");
-    }
+    // grouped ordering: 8 tile-rows at a time, column-major inside a group
+    auto tile_of = [&](int wg, int& tm, int& tn) {
+        const int GROUP = 8;
+        const int group_sz = GROUP * tiles_n;
+        const int gid = wg / group_sz;
+        const int first_m = gid * GROUP;
+        const int gm = min(GROUP, tiles_m - first_m);
+        tm = first_m + (wg % group_sz) % gm;
+        tn = (wg % group_sz) / gm;
+    };
 
-    // ---- epilogue: through LDS, so that C leaves in full 16-byte pieces of contiguous rows --------------------
-    // D layout of v_mfma_f32_32x32x16 with the operands swapped: lane (frow, fhalf) holds row frow of the 32 x 32 block,
-    // register e holds column (e & 3) + 8 (e >> 2) + 4 fhalf: four groups of 4 consecutive columns.  Each group is
-    // converted and written to an LDS image of the tile ([row][col], rows padded by 16 B); then every thread copies
-    // 16-byte pieces of rows to global memory (one wave instruction = 1 KiB of contiguous C).  Storing the
-    // accumulators directly costs one 2-byte store per element: 1024 wave-wide store instructions per 256 x 256 tile,
-    // as long as the tile's MFMA work.  fp32 C does not fit in one LDS image: one pass per wave row.
-    {
-        constexpr int ESZ = (int)sizeof(OT);
-        constexpr int RS = TBN * ESZ + 16;                              // LDS row stride
-        constexpr int PASSES = (ESZ == 2) ? 1 : WAVES_M;
-        constexpr int PASS_ROWS = TBM / PASSES;
-        constexpr int CH = TBN * ESZ / 16;                              // 16-byte pieces per row
-        for (int pass = 0; pass < PASSES; ++pass) {
-            if (PASSES == 1 || wr == pass) {
-                const int row0 = (PASSES == 1) ? wr * (WM * 32) : 0;
+    int tm, tn;
+    tile_of(t, tm, tn);
+    const bf16_t* Ag = A + (int64_t)tm * TBM * lda;
+    const bf16_t* Bg = B + (int64_t)tn * TBN * ldb;
+    stage_tile<TBM, WAVES>(Ag, lda, ring, wave, lane);
+    stage_tile<TBN, WAVES>(Bg, ldb, ring + TILE_BYTES, wave, lane);
+    int slot = 0;
+    bool landed = false;  // the current slot's k-tile was already waited for (at the previous tile's epilogue)
+
+    for (;;) {
+        const int t_next = t + stride;
+        const bool more = t_next < xcd_end;
+        int tm2 = 0, tn2 = 0;
+        if (more) tile_of(t_next, tm2, tn2);
+        const bf16_t* Ag2 = A + (int64_t)tm2 * TBM * lda;
+        const bf16_t* Bg2 = B + (int64_t)tn2 * TBN * ldb;
+
+        f32x16 acc[WM][WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        for (int kt = 0; kt < k_tiles; ++kt) {
+            char* cur = ring + slot * STAGE_BYTES;
+            char* nxt = ring + (slot ^ 1) * STAGE_BYTES;
+            const bool in_tile = kt + 1 < k_tiles;
+            if (in_tile) {
+                stage_tile<TBM, WAVES>(Ag + (int64_t)(kt + 1) * BK, lda, nxt, wave, lane);
+                stage_tile<TBN, WAVES>(Bg + (int64_t)(kt + 1) * BK, ldb, nxt + TILE_BYTES, wave, lane);
+            } else if (more) {
+                stage_tile<TBM, WAVES>(Ag2, lda, nxt, wave, lane);
+                stage_tile<TBN, WAVES>(Bg2, ldb, nxt + TILE_BYTES, wave, lane);
+            }
+            if (!landed) {
+                // k-tile `cur` landed; the one just issued (LOADS_PER_STAGE DMAs of this wave) stays in flight across
+                // the barrier.  (vmcnt also counts the previous tile's stores, all older than the DMAs waited for.)
+                static_assert(LOADS_PER_STAGE == 4 || LOADS_PER_STAGE == 8 || LOADS_PER_STAGE == 16, "the counted vmcnt below assumes 4, 8 or 16 LDS-DMA instructions per wave per stage");
+                if (in_tile || more) {
+                    if (LOADS_PER_STAGE == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else if (LOADS_PER_STAGE == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            }
+            landed = false;
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8 a[WM];
+#pragma unroll
+                for (int i = 0; i < WM; ++i) a[i] = read_frag(cur, wr * (WM * 32) + i * 32 + frow, ks * 2 + fhalf);
+                bf16x8 b[WN];
+#pragma unroll
+                for (int j = 0; j < WN; ++j) b[j] = read_frag(cur + TILE_BYTES, wc * (WN * 32) + j * 32 + frow, ks * 2 + fhalf);
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
                     for (int j = 0; j < WN; ++j)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            char* dst = lds + (row0 + i * 32 + frow) * RS + (wc * (WN * 32) + j * 32 + 8 * g + 4 * fhalf) * ESZ;
-                            if (ESZ == 2) {
-                                typedef __attribute__((ext_vector_type(4))) _Float16 h4;
-                                h4 v;
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] = (_Float16)fminf(fmaxf(acc[i][j][4 * g + e], -1.0f), 1.0f);  // (see api.cpp: eps_rest)
-                                *reinterpret_cast<h4*>(dst) = v;
-                            } else {
-                                *reinterpret_cast<float4*>(dst) = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-                            }
-                        }
+                        // operands swapped (D' = B A^T): a lane then holds ONE row of S and groups of 4 consecutive columns
+                        acc[i][j] = mfma<F16>(b[j], a[i], acc[i][j]);
             }
-            __syncthreads();
-            OT* Cg = C + ((int64_t)tm * TBM + pass * PASS_ROWS) * ldc + (int64_t)tn * TBN;
-            for (int idx = threadIdx.x; idx < PASS_ROWS * CH; idx += WAVES * 64) {
-                const int row = idx / CH, ch = idx - row * CH;
-                const uint4 v = *reinterpret_cast<const uint4*>(lds + row * RS + ch * 16);
-                *reinterpret_cast<uint4*>(reinterpret_cast<char*>(Cg + (int64_t)row * ldc) + ch * 16) = v;
-            }
-            if (pass + 1 < PASSES) __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // everyone is done reading `cur` before it is restaged
+            asm volatile("" ::: "memory");
+            slot ^= 1;
         }
+
+        // ---- epilogue: through LDS, so that C leaves in full 16-byte pieces of contiguous rows ----------------
+        // D layout of v_mfma_f32_32x32x16 with the operands swapped: lane (frow, fhalf) holds row frow of the 32 x 32
+        // block, register e holds column (e & 3) + 8 (e >> 2) + 4 fhalf: four groups of 4 consecutive columns.  Each
+        // group is converted and written to an LDS image of PASS_ROWS rows of the tile ([row][col], rows padded by
+        // 16 B); then every thread copies 16-byte pieces of rows to global memory (one wave instruction = 1 KiB of
+        // contiguous C).  Storing the accumulators directly costs one 2-byte store per element: 1024 wave-wide store
+        // instructions per 256 x 256 tile, as long as the tile's MFMA work.
+        {
+            // the next tile's first k-tile (issued one MFMA step ago) lands before any store is queued behind it
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            landed = more;
+            constexpr int ESZ = EG::ESZ, RS = EG::RS, IPP = EG::IPP, PASS_ROWS = EG::PASS_ROWS, PASSES = EG::PASSES;
+            constexpr int CH = TBN * ESZ / 16;                              // 16-byte pieces per row
+            // the consumed slot is slot ^ 1; its image may extend into the PAD on its outer side
+            char* const img = (slot ^ 1) ? ring + STAGE_BYTES : lds;
+#pragma unroll
+            for (int pass = 0; pass < PASSES; ++pass) {
+                const int wrp = pass / (WM / IPP), i0 = (pass % (WM / IPP)) * IPP;
+                if (wr == wrp) {
+#pragma unroll
+                    for (int ii = 0; ii < IPP; ++ii)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const int i = i0 + ii;
+                                char* dst = img + (ii * 32 + frow) * RS + (wc * (WN * 32) + j * 32 + 8 * g + 4 * fhalf) * ESZ;
+                                if (ESZ == 2) {
+                                    typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+                                    h4 v;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] = (_Float16)fminf(fmaxf(acc[i][j][4 * g + e], -1.0f), 1.0f);  // (see api.cpp: eps_rest)
+                                    *reinterpret_cast<h4*>(dst) = v;
+                                } else {
+                                    *reinterpret_cast<float4*>(dst) = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                                }
+                            }
+                }
+                __syncthreads();
+                OT* Cg = C + ((int64_t)tm * TBM + wrp * (WM * 32) + i0 * 32) * ldc + (int64_t)tn * TBN;
+                for (int idx = threadIdx.x; idx < PASS_ROWS * CH; idx += WAVES * 64) {
+                    const int row = idx / CH, ch = idx - row * CH;
+                    const uint4 v = *reinterpret_cast<const uint4*>(img + row * RS + ch * 16);
+                    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+                    // C is written once and read back only after the whole panel: keep it from displacing A/B in the L2
+                    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(reinterpret_cast<char*>(Cg + (int64_t)row * ldc) + ch * 16));
+                }
+                __syncthreads();  // the image is rewritten by the next pass / restaged by the next tile
+            }
+        }
+        if (!more) break;
+        t = t_next;
+        tm = tm2;
+        tn = tn2;
+        Ag = Ag2;
+        Bg = Bg2;
     }
 }
 
@@ -239,17 +304,23 @@ template <bool F16, class OT, int WM, int WN, int WAVES_M, int WAVES_N>
 static void launch_gemm_cfg(const bf16_t* A, const bf16_t* B, OT* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                             int64_t ldb, int64_t ldc, hipStream_t st) {
     constexpr int TB = WAVES_M * WM * 32;
-    constexpr int EPI = (TB / (sizeof(OT) == 2 ? 1 : WAVES_M)) * (TB * (int)sizeof(OT) + 16);  // epilogue image of the tile
-    constexpr int SMEM = 2 * TileGeom<TB>::STAGE_BYTES > EPI ? 2 * TileGeom<TB>::STAGE_BYTES : EPI;
+    constexpr int SMEM = EpiGeom<OT, WM, WAVES_M, TB>::SMEM;
+    static_assert(SMEM <= 160 * 1024, "gemm: LDS plan exceeds the CU's 160 KiB");
     const int64_t tiles = (M / TB) * (N / TB);
     KN_REQUIRE(tiles > 0 && tiles < (1ll << 31), KNNCF_E_INVALID, "gemm: grid too large");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static int slots = 0;  // resident workgroups on the device
+    if (!slots) {
         KN_HIP(hipFuncSetAttribute((const void*)k_gemm_nt_bf16<F16, OT, WM, WN, WAVES_M, WAVES_N>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-        attr_set = true;
+        int dev = 0, cus = 0, per_cu = 0;
+        KN_HIP(hipGetDevice(&dev));
+        KN_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        KN_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gemm_nt_bf16<F16, OT, WM, WN, WAVES_M, WAVES_N>,
+                                                            WAVES_M * WAVES_N * 64, SMEM));
+        slots = cus * (per_cu > 0 ? per_cu : 1);
     }
-    k_gemm_nt_bf16<F16, OT, WM, WN, WAVES_M, WAVES_N><<<(unsigned)tiles, WAVES_M * WAVES_N * 64, SMEM, st>>>(
+    const unsigned grid = (unsigned)(tiles < slots ? tiles : slots);
+    k_gemm_nt_bf16<F16, OT, WM, WN, WAVES_M, WAVES_N><<<grid, WAVES_M * WAVES_N * 64, SMEM, st>>>(
         A, B, C, (int)(M / TB), (int)(N / TB), (int)(K / BK), lda, ldb, ldc);
     KN_HIP(hipGetLastError());
 }
@@ -260,6 +331,7 @@ static void launch_gemm_t(const bf16_t* A, const bf16_t* B, OT* C, int64_t M, in
     // (a 4-wave variant of the large tile, each wave a 128 x 128 sub-tile in 256 accumulator registers — a third
     // less LDS read traffic per flop — measured the same: 30.6 vs 30.7 ms at K = 448, 52.8 vs 51.9 ms at K = 1024)
     static const bool force_small = getenv("KNNCF_GEMM_TILE128") != nullptr;  // A/B switch for measurements
+    // (16 waves on the 256 x 256 tile, each a 64 x 64 sub-tile, 4 waves per SIMD: 8.3 vs 6.9 ms per launch at K = 256)
     if (M % 256 == 0 && N % 256 == 0 && !force_small) launch_gemm_cfg<F16, OT, 4, 2, 2, 4>(A, B, C, M, N, K, lda, ldb, ldc, st);
     else launch_gemm_cfg<F16, OT, 2, 2, 2, 2>(A, B, C, M, N, K, lda, ldb, ldc, st);
 }
