@@ -86,8 +86,8 @@ struct PrepScratch {
     DArr<uint32_t> status;  // [4] device status words
     DArr<double> dsum;      // small reduction scratch
     // side streams for the three independent item folds of prep_commit (created on first use)
-    hipStream_t aux[2] = {nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    hipStream_t aux[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     void release_all();
     ~PrepScratch();
 };

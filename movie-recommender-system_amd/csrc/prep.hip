@@ -26,7 +26,7 @@ void PrepScratch::release_all() {
 }
 
 PrepScratch::~PrepScratch() {
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 3; ++i) {
         if (aux[i]) (void)hipStreamDestroy(aux[i]);
         if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
     }
@@ -541,6 +541,37 @@ __global__ void k_pop_keys(int32_t I, const int64_t* __restrict__ i_ptr, uint64_
 void prep_commit(Train& tr, PrepScratch& sc, hipStream_t st) {
     const int64_t n = tr.n;
     const int32_t I = tr.I;
+    // Three independent ordered folds over the item segments.  Each is bound by the serial fp64 chain of its longest
+    // segment (an item with 0.4 % of all ratings), not by bandwidth: they run side by side on three streams, forked
+    // here and joined at the end, under the item-major copies and the bitmaps that this stream builds meanwhile.  (HIP
+    // maps streams of one priority onto few hardware queues — two of three equal-priority streams shared one and ran
+    // back to back — so the three streams get the three priority levels.)
+    tr.item_avg.alloc(I); tr.item_dev_hash.alloc(I); tr.item_dev_file.alloc(I);
+    const size_t slab = (size_t)I + 2;
+    sc.dsum.ensure(3 * slab);
+    if (!sc.aux[0]) {
+        int prio_least = 0, prio_greatest = 0;
+        KN_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        const int prio[3] = {prio_greatest, (prio_least + prio_greatest) / 2, prio_least};
+        for (int i = 0; i < 3; ++i) {
+            KN_HIP(hipStreamCreateWithPriority(&sc.aux[i], hipStreamNonBlocking, prio[i]));
+            KN_HIP(hipEventCreateWithFlags(&sc.ev_join[i], hipEventDisableTiming));
+        }
+        KN_HIP(hipEventCreateWithFlags(&sc.ev_fork, hipEventDisableTiming));
+    }
+    KN_HIP(hipEventRecord(sc.ev_fork, st));
+    for (int i = 0; i < 3; ++i) KN_HIP(hipStreamWaitEvent(sc.aux[i], sc.ev_fork, 0));
+    // itemsAvg :134
+    fold<false>(tr.i_ptr.p, 0, I, tr.perm_if.p, tr.s_rating.p, sc.dsum.p, sc.aux[0], 16);
+    k_divide_by_count<<<nblocks(I), TPB, 0, sc.aux[0]>>>(tr.i_ptr.p, 0, I, sc.dsum.p, tr.item_avg.p);
+    // getItemsAvgDev :336-343 (reduceByKey, modelled in file order)
+    fold<false>(tr.i_ptr.p, 0, I, tr.perm_if.p, tr.s_dev.p, sc.dsum.p + slab, sc.aux[1], 16);
+    k_divide_by_count<<<nblocks(I), TPB, 0, sc.aux[1]>>>(tr.i_ptr.p, 0, I, sc.dsum.p + slab, tr.item_dev_file.p);
+    // itemsAvgDev :176-186 (foldLeft over the HashMap: trie order of the (user,item) hashes)
+    fold<false>(tr.i_ptr.p, 0, I, n > 4 ? tr.perm_ih.p : tr.perm_if.p, tr.s_dev.p, sc.dsum.p + 2 * slab, sc.aux[2], 16);
+    k_divide_by_count<<<nblocks(I), TPB, 0, sc.aux[2]>>>(tr.i_ptr.p, 0, I, sc.dsum.p + 2 * slab, tr.item_dev_hash.p);
+    for (int i = 0; i < 3; ++i) KN_HIP(hipEventRecord(sc.ev_join[i], sc.aux[i]));
+    KN_HIP(hipGetLastError());
     // item-major copies + popularity order (hybrid similarity: dense head / sparse tail)
     // (item, user ascending) order: a stable sort of the user-major positions by item
     tr.it_user.alloc(n); tr.it_pack.alloc(n); tr.it_dev.alloc(n); tr.it_t.alloc(n); tr.pop_item.alloc(I);
@@ -585,33 +616,7 @@ void prep_commit(Train& tr, PrepScratch& sc, hipStream_t st) {
         tr.pop_count.resize(I);
         for (int32_t i = 0; i < I; ++i) tr.pop_count[i] = (int64_t)~hk[i];
     }
-    tr.item_avg.alloc(I); tr.item_dev_hash.alloc(I); tr.item_dev_file.alloc(I);
-    // Three independent ordered folds over the item segments.  Each is bound by the serial fp64 chain of its longest
-    // segment (an item with 0.4 % of all ratings), not by bandwidth, so they run side by side on three streams.
-    const size_t slab = (size_t)I + 2;
-    sc.dsum.ensure(3 * slab);
-    if (!sc.aux[0]) {
-        for (int i = 0; i < 2; ++i) {
-            KN_HIP(hipStreamCreateWithFlags(&sc.aux[i], hipStreamNonBlocking));
-            KN_HIP(hipEventCreateWithFlags(&sc.ev_join[i], hipEventDisableTiming));
-        }
-        KN_HIP(hipEventCreateWithFlags(&sc.ev_fork, hipEventDisableTiming));
-    }
-    KN_HIP(hipEventRecord(sc.ev_fork, st));
-    for (int i = 0; i < 2; ++i) KN_HIP(hipStreamWaitEvent(sc.aux[i], sc.ev_fork, 0));
-    // itemsAvg :134
-    fold<false>(tr.i_ptr.p, 0, I, tr.perm_if.p, tr.s_rating.p, sc.dsum.p, st, 16);
-    k_divide_by_count<<<nblocks(I), TPB, 0, st>>>(tr.i_ptr.p, 0, I, sc.dsum.p, tr.item_avg.p);
-    // getItemsAvgDev :336-343 (reduceByKey, modelled in file order)
-    fold<false>(tr.i_ptr.p, 0, I, tr.perm_if.p, tr.s_dev.p, sc.dsum.p + slab, sc.aux[0], 16);
-    k_divide_by_count<<<nblocks(I), TPB, 0, sc.aux[0]>>>(tr.i_ptr.p, 0, I, sc.dsum.p + slab, tr.item_dev_file.p);
-    // itemsAvgDev :176-186 (foldLeft over the HashMap: trie order of the (user,item) hashes)
-    fold<false>(tr.i_ptr.p, 0, I, n > 4 ? tr.perm_ih.p : tr.perm_if.p, tr.s_dev.p, sc.dsum.p + 2 * slab, sc.aux[1], 16);
-    k_divide_by_count<<<nblocks(I), TPB, 0, sc.aux[1]>>>(tr.i_ptr.p, 0, I, sc.dsum.p + 2 * slab, tr.item_dev_hash.p);
-    for (int i = 0; i < 2; ++i) {
-        KN_HIP(hipEventRecord(sc.ev_join[i], sc.aux[i]));
-        KN_HIP(hipStreamWaitEvent(st, sc.ev_join[i], 0));
-    }
+    for (int i = 0; i < 3; ++i) KN_HIP(hipStreamWaitEvent(st, sc.ev_join[i], 0));
     KN_HIP(hipGetLastError());
 }
 
