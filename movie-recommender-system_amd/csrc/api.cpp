@@ -327,7 +327,9 @@ void build_neighbors(knncf_handle* h, int32_t count) {
     // there, so clamping only moves towards it), where half an fp16 ulp is at most 2^-12
     const float eps_opnd = gemm_eps_operand(fp16);
     const float eps_rest = gemm_eps_rest(fp16) + (s_fp16 ? 2.45e-4f : 0.f);
-    hipStream_t sp = h->stream2;  // producer: densify, GEMM, sparse tail
+    // producer: densify, GEMM.  Without the overlap it is the consumer's stream itself: an event wait across two
+    // hardware queues costs ~0.1 ms each time (three blocks per step at ml-25m shape)
+    hipStream_t sp = slots > 1 ? h->stream2 : h->stream;
     hipStream_t sc = h->stream;   // consumer: select, exact re-rank
     KN_HIP(hipEventRecord(h->ev_ready, sc));  // everything queued so far (fit, B panel) precedes the producer
     KN_HIP(hipStreamWaitEvent(sp, h->ev_ready, 0));
