@@ -214,6 +214,26 @@ def test_hybrid_head_tail_split_is_exact(kn, oracle, syn100k, head, bf16):
         assert ids.tolist() == oids.tolist() and sims.tolist() == osims.tolist()
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+def test_fp32_panel_gives_the_same_neighbours(kn, oracle, syn100k, bf16):
+    """KNNCF_FLAG_F32_PANEL: the GEMM's fp32 epilogue (four LDS passes per tile) and the select kernel's fp32 loads —
+    a narrower error band, the same exact neighbours and predictions."""
+    d = syn100k
+    tr = (d.train.users, d.train.items, d.train.ratings)
+    te = (d.test.users, d.test.items, d.test.ratings)
+    p = oracle.Model(*tr).pipeline(oracle.SIM_COSINE, 50)
+    want, preds = p.mae(*te, True)
+    e = _engine(kn, tr, k=50, flags=kn.FLAG_VERIFY_BOUND | kn.FLAG_F32_PANEL | (kn.FLAG_BF16_FILTER if bf16 else 0), head_items=320)
+    np.testing.assert_array_equal(e.predict_batch(kn.PRED_KNN, te[0], te[1]), preds)
+    assert abs(e.mae(kn.PRED_KNN, *te) - want) <= MAE_TOL
+    assert e.timings()["max_bound_violation"] <= 0.0
+    for u in np.unique(d.train.users)[::37]:
+        ids, sims = e.neighbors(int(u))
+        oids, osims = p.neighbors(int(u))
+        assert ids.tolist() == oids.tolist() and sims.tolist() == osims.tolist()
+    e.close()
+
+
 def test_two_shards_on_one_gpu_equal_single_engine(kn, pkg, oracle, synth):
     """The C-ABI shard protocol (view -> exchange -> commit -> partial MAE) with two handles in one
     process; the exchange that RCCL's all-gather performs between GPUs is done here by device copies."""
