@@ -689,8 +689,6 @@ void launch_tail_select(const Train& tr, const int32_t* d_colmap, bool has_tail,
     int32_t kk = k < U - 1 ? k : U - 1;
     if (kk < 1) kk = 1;
     KN_REQUIRE(!has_tail || tr.tile_stride == (int32_t)ceil_div(U, TCOLS) + 1, KNNCF_E_STATE, "select: tile table missing");
-    static const bool debug_no_tail = getenv("KNNCF_DEBUG_NO_TAIL") != nullptr;  // timing experiments only: wrong results
-    if (debug_no_tail) has_tail = false;
     TailArgs T{tr.u_ptr.p, tr.s_col.p, tr.s_pre.p, d_colmap, tr.i_ptr.p, tr.it_pack.p, (uint32_t)(tr.n * 4), tr.it_tile.p, tr.tile_stride, has_tail ? 1 : 0};
     if (s_fp16) launch_tail_select_t(T, static_cast<const _Float16*>(S), lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, st);
     else launch_tail_select_t(T, static_cast<const float*>(S), lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, st);
