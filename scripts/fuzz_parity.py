@@ -34,7 +34,7 @@ for seed in range(first, first + count):
     if len(te[0]) == 0:
         continue
     k = int(rng.choice([1, 2, 5, 17, 64, 300, 1000]))
-    flags = int(rng.choice([0, 1, 4, 8, 5, 9, 12, 13]))
+    flags = int(rng.choice([0, 1, 4, 8, 5, 9, 12, 13, 2, 3, 7, 10]))
     head = int(rng.choice([0, 1, 7, 64, 0xFFFFFFFF]))
     m = oracle.Model(*tr)
     p = m.pipeline(oracle.SIM_COSINE, k)

@@ -234,6 +234,28 @@ def test_fp32_panel_gives_the_same_neighbours(kn, oracle, syn100k, bf16):
     e.close()
 
 
+@pytest.mark.parametrize("flags", [0, 2])
+def test_several_row_blocks_and_the_overlap_flag(kn, oracle, syn100k, flags):
+    """A small workspace cuts the users into 256-row blocks (4 at ml-100k shape); KNNCF_FLAG_OVERLAP (= 2) then runs
+    the GEMM of block b + 1 on a second stream into a second panel slot while block b is selected and re-ranked."""
+    d = syn100k
+    tr = (d.train.users, d.train.items, d.train.ratings)
+    te = (d.test.users, d.test.items, d.test.ratings)
+    p = oracle.Model(*tr).pipeline(oracle.SIM_COSINE, 50)
+    want, preds = p.mae(*te, True)
+    e = kn.Engine(k=50, flags=flags | kn.FLAG_VERIFY_BOUND, head_items=128, workspace_bytes=1 << 20)
+    e.fit(*tr)
+    np.testing.assert_array_equal(e.predict_batch(kn.PRED_KNN, te[0], te[1]), preds)
+    assert abs(e.mae(kn.PRED_KNN, *te) - want) <= MAE_TOL
+    t = e.timings()
+    assert t["gemm_launches"] >= 4 and t["max_bound_violation"] <= 0.0
+    for u in np.unique(d.train.users)[::29]:
+        ids, sims = e.neighbors(int(u))
+        oids, osims = p.neighbors(int(u))
+        assert ids.tolist() == oids.tolist() and sims.tolist() == osims.tolist()
+    e.close()
+
+
 def test_two_shards_on_one_gpu_equal_single_engine(kn, pkg, oracle, synth):
     """The C-ABI shard protocol (view -> exchange -> commit -> partial MAE) with two handles in one
     process; the exchange that RCCL's all-gather performs between GPUs is done here by device copies."""
