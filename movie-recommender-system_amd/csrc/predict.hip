@@ -422,8 +422,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_predict_knn_rows(PredArgs A, int
 // of the item's 20 KB bitmap row, ~38 KB of L2 -> L1 traffic per prediction, and the kernels above are bound by exactly
 // that (19 TB/s of sector traffic at ml-25m shape).  Here the test rows are SORTED BY ITEM and a workgroup keeps the
 // current item's bitmap + rank prefixes in LDS (30 KB): it is fetched once per run of rows of that item, the probes
-// become LDS reads, and what remains in global memory is the coalesced stream of each row's neighbour list and the
-// gathers of the ~14 matched ratings.
+// become LDS reads, and what remains in global memory is the coalesced stream of each row's neighbour ids and the
+// gathers of the ~14 matched ratings and similarities.
 template <int TR, int G, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) k_predict_knn_items(PredArgs A, int64_t n, const int32_t* __restrict__ du,
                                                               const int32_t* __restrict__ di, const double* __restrict__ ratings,
@@ -493,6 +493,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_predict_knn_items(PredArgs A, in
                 uint32_t rbase[G];
                 uint32_t x[G][TR];
                 u32x2 sv[G][TR];
+                __amdgpu_buffer_rsrc_t r_usim[G];
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     const int rr = rg + g;
@@ -503,12 +504,11 @@ __global__ void __launch_bounds__(WAVES * 64) k_predict_knn_items(PredArgs A, in
                     rbase[g] = (uint32_t)__builtin_amdgcn_readfirstlane(on ? (int)s_rb[rr] : 0);
                     const int64_t base = (int64_t)u * A.kcap;
                     const auto r_uidx = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(uniform_ptr(A.nbr_uidx + base)), 0, (uint32_t)cnts[g] * 4u, 0x00020000);
-                    const auto r_usim = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(uniform_ptr(A.nbr_usim + base)), 0, (uint32_t)cnts[g] * 8u, 0x00020000);
+                    r_usim[g] = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(uniform_ptr(A.nbr_usim + base)), 0, (uint32_t)cnts[g] * 8u, 0x00020000);
 #pragma unroll
-                    for (int k = 0; k < TR; ++k) {  // the row's neighbours (ids ascending) and similarities; past cnt: 0
+                    for (int k = 0; k < TR; ++k) {  // the row's neighbours (ids ascending); past cnt: 0
                         const uint32_t j = 64u * k + lane;
                         x[g][k] = __builtin_amdgcn_raw_buffer_load_b32(r_uidx, (int)(j * 4u), 0, 0);
-                        sv[g][k] = __builtin_amdgcn_raw_buffer_load_b64(r_usim, (int)(j * 8u), 0, 0);
                     }
                 }
                 u32x2 dv[G][TR];
@@ -529,6 +529,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_predict_knn_items(PredArgs A, in
                         const uint32_t q = f ? rbase[g] + before + (uint32_t)__popcll(word & ((1ull << (xi & 63u)) - 1ull)) : 0x0fffffffu;
                         mtv[g][k] = __builtin_amdgcn_raw_buffer_load_b32(r_t, (int)(q * 4u), 0, 0);
                         dv[g][k] = __builtin_amdgcn_raw_buffer_load_b64(r_dev, (int)(q * 8u), 0, 0);
+                        // the similarity is needed for the ~5 % of neighbours that rated the item only: it is gathered
+                        // with the ratings instead of streamed with the ids (a third of the list bytes instead of all)
+                        sv[g][k] = __builtin_amdgcn_raw_buffer_load_b64(r_usim[g], f ? (int)((64u * k + lane) * 8u) : -1, 0, 0);
                     }
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
