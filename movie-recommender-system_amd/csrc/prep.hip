@@ -76,15 +76,16 @@ __global__ void k_scatter_raw_ids(int64_t n, const int32_t* __restrict__ raw, co
     out[dense[t]] = raw[t];
 }
 
-// mode 0: key = du<<32 | di ; 1: du ; 2: du<<32 | tuple key ; 3: di ; 4: di<<32 | tuple key
+// mode 0: key = du<<lo_bits | di (di < 2^lo_bits: the fewer key bits, the fewer radix passes) ; 1: du ;
+// 2: du<<32 | tuple key ; 3: di ; 4: di<<32 | tuple key
 __global__ void k_make_keys(int64_t n, int mode, const int32_t* __restrict__ du, const int32_t* __restrict__ di,
                             const int32_t* __restrict__ users, const int32_t* __restrict__ items,
-                            uint64_t* __restrict__ key) {
+                            uint64_t* __restrict__ key, int lo_bits) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     uint64_t k;
     switch (mode) {
-        case 0: k = ((uint64_t)(uint32_t)du[t] << 32) | (uint32_t)di[t]; break;
+        case 0: k = ((uint64_t)(uint32_t)du[t] << lo_bits) | (uint32_t)di[t]; break;
         case 1: k = (uint32_t)du[t]; break;
         case 2: k = ((uint64_t)(uint32_t)du[t] << 32) | tuple_trie_key(users[t], items[t]); break;
         case 3: k = (uint32_t)di[t]; break;
@@ -100,12 +101,12 @@ __global__ void k_iota(int64_t n, uint32_t* __restrict__ v) {
 
 // unpack the sorted (user, item) keys; flag duplicate (user, item) rows
 __global__ void k_unpack_positions(int64_t n, const uint64_t* __restrict__ key, int32_t* __restrict__ s_user,
-                                   int32_t* __restrict__ s_col, uint32_t* __restrict__ status) {
+                                   int32_t* __restrict__ s_col, uint32_t* __restrict__ status, int lo_bits) {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     uint64_t k = key[p];
-    s_user[p] = (int32_t)(k >> 32);
-    s_col[p] = (int32_t)(k & 0xffffffffu);
+    s_user[p] = (int32_t)(k >> lo_bits);
+    s_col[p] = (int32_t)(k & ((1ull << lo_bits) - 1ull));
     if (p > 0 && key[p - 1] == k) atomicOr(status, (uint32_t)ST_DUPLICATE);
 }
 
@@ -373,12 +374,12 @@ void prep_fit(Train& tr, PrepScratch& sc, int32_t shard_rank, int32_t shard_coun
     // canonical user-major order: sort file rows by (user, item)
     tr.s_user.alloc(n); tr.s_col.alloc(n); tr.s_t.alloc(n); tr.s_rating.alloc(n);
     tr.s_dev.alloc(n); tr.s_pre.alloc(n); tr.u_ptr.alloc(U + 1); tr.i_ptr.alloc(I + 1);
-    k_make_keys<<<nblocks(n), TPB, 0, st>>>(n, 0, sc.du_row.p, sc.di_row.p, tr.user_raw.p, tr.item_raw.p, sc.k64_a.p);
+    k_make_keys<<<nblocks(n), TPB, 0, st>>>(n, 0, sc.du_row.p, sc.di_row.p, tr.user_raw.p, tr.item_raw.p, sc.k64_a.p, ibits);
     k_iota<<<nblocks(n), TPB, 0, st>>>(n, sc.v32_a.p);
     KN_HIP(hipGetLastError());
-    sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.v32_a.p, tr.s_t.p, n, 32 + ubits, st);
-    k_unpack_positions<<<nblocks(n), TPB, 0, st>>>(n, sc.k64_b.p, tr.s_user.p, tr.s_col.p, sc.status.p);
-    k_segment_ptr<<<nblocks((int64_t)U + 1), TPB, 0, st>>>(n, sc.k64_b.p, 32, tr.U, tr.u_ptr.p);
+    sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.v32_a.p, tr.s_t.p, n, ibits + ubits, st);
+    k_unpack_positions<<<nblocks(n), TPB, 0, st>>>(n, sc.k64_b.p, tr.s_user.p, tr.s_col.p, sc.status.p, ibits);
+    k_segment_ptr<<<nblocks((int64_t)U + 1), TPB, 0, st>>>(n, sc.k64_b.p, ibits, tr.U, tr.u_ptr.p);
     k_gather_f64<<<nblocks(n), TPB, 0, st>>>(n, tr.s_t.p, tr.rating.p, tr.s_rating.p);
     sc.perm_f.ensure(n);
     k_invert<<<nblocks(n), TPB, 0, st>>>(n, tr.s_t.p, sc.perm_f.p);
@@ -386,17 +387,17 @@ void prep_fit(Train& tr, PrepScratch& sc, int32_t shard_rank, int32_t shard_coun
 
     // fold orders: stable sorts of the file-order sequence of positions
     tr.perm_uf.alloc(n); tr.perm_if.alloc(n);
-    k_make_keys<<<nblocks(n), TPB, 0, st>>>(n, 1, sc.du_row.p, sc.di_row.p, tr.user_raw.p, tr.item_raw.p, sc.k64_a.p);
+    k_make_keys<<<nblocks(n), TPB, 0, st>>>(n, 1, sc.du_row.p, sc.di_row.p, tr.user_raw.p, tr.item_raw.p, sc.k64_a.p, 32);
     sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.perm_f.p, tr.perm_uf.p, n, ubits, st);
-    k_make_keys<<<nblocks(n), TPB, 0, st>>>(n, 3, sc.du_row.p, sc.di_row.p, tr.user_raw.p, tr.item_raw.p, sc.k64_a.p);
+    k_make_keys<<<nblocks(n), TPB, 0, st>>>(n, 3, sc.du_row.p, sc.di_row.p, tr.user_raw.p, tr.item_raw.p, sc.k64_a.p, 32);
     sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.perm_f.p, tr.perm_if.p, n, ibits, st);
     k_segment_ptr<<<nblocks((int64_t)I + 1), TPB, 0, st>>>(n, sc.k64_b.p, 0, tr.I, tr.i_ptr.p);
     KN_HIP(hipGetLastError());
     if (n > 4) {  // a Map of <= 4 entries (Map1..Map4) iterates in insertion = file order (N4)
         tr.perm_uh.alloc(n); tr.perm_ih.alloc(n);
-        k_make_keys<<<nblocks(n), TPB, 0, st>>>(n, 2, sc.du_row.p, sc.di_row.p, tr.user_raw.p, tr.item_raw.p, sc.k64_a.p);
+        k_make_keys<<<nblocks(n), TPB, 0, st>>>(n, 2, sc.du_row.p, sc.di_row.p, tr.user_raw.p, tr.item_raw.p, sc.k64_a.p, 32);
         sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.perm_f.p, tr.perm_uh.p, n, 32 + ubits, st);
-        k_make_keys<<<nblocks(n), TPB, 0, st>>>(n, 4, sc.du_row.p, sc.di_row.p, tr.user_raw.p, tr.item_raw.p, sc.k64_a.p);
+        k_make_keys<<<nblocks(n), TPB, 0, st>>>(n, 4, sc.du_row.p, sc.di_row.p, tr.user_raw.p, tr.item_raw.p, sc.k64_a.p, 32);
         sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.perm_f.p, tr.perm_ih.p, n, 32 + ibits, st);
     } else {
         tr.perm_uh.release();
