@@ -19,10 +19,13 @@ static constexpr int SELECT_TCOLS = 16384;  // <= 2^15: it_pack keeps the LDS ce
 // ---- sort_util.hip (rocPRIM device radix sort / unique; K0 plumbing only) ---------------
 struct SortWorkspace {
     DArr<char> tmp;
+    DArr<size_t> count;  // result cell of unique_u32 (kept: a hipFree per call synchronises the device)
 };
 void sort_pairs_u64_u32(SortWorkspace& ws, const uint64_t* kin, uint64_t* kout, const uint32_t* vin,
                         uint32_t* vout, size_t n, int end_bit, hipStream_t st);
 void sort_keys_u32(SortWorkspace& ws, const uint32_t* kin, uint32_t* kout, size_t n, hipStream_t st);
+void sort_pairs_u32_u32(SortWorkspace& ws, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout, size_t n,
+                        int end_bit, hipStream_t st);
 // out must hold n entries; returns the number of distinct values (synchronises the stream)
 size_t unique_u32(SortWorkspace& ws, const uint32_t* sorted_in, uint32_t* out, size_t n, hipStream_t st);
 

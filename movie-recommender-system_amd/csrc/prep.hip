@@ -94,6 +94,25 @@ __global__ void k_make_keys(int64_t n, int mode, const int32_t* __restrict__ du,
     key[t] = k;
 }
 
+// 32-bit keys for the two plain fold orders (a third less sort traffic than 64-bit keys)
+__global__ void k_copy_keys_u32(int64_t n, const int32_t* __restrict__ dense, uint32_t* __restrict__ key) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) key[t] = (uint32_t)dense[t];
+}
+
+// ptr[s] = first index whose key >= s, s in [0, S]
+__global__ void k_segment_ptr_u32(int64_t n, const uint32_t* __restrict__ sorted_key, int32_t S, int64_t* __restrict__ ptr) {
+    int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > S) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (sorted_key[mid] < (uint32_t)s) lo = mid + 1;
+        else hi = mid;
+    }
+    ptr[s] = lo;
+}
+
 __global__ void k_iota(int64_t n, uint32_t* __restrict__ v) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n) v[t] = (uint32_t)t;
@@ -387,11 +406,11 @@ void prep_fit(Train& tr, PrepScratch& sc, int32_t shard_rank, int32_t shard_coun
 
     // fold orders: stable sorts of the file-order sequence of positions
     tr.perm_uf.alloc(n); tr.perm_if.alloc(n);
-    k_make_keys<<<nblocks(n), TPB, 0, st>>>(n, 1, sc.du_row.p, sc.di_row.p, tr.user_raw.p, tr.item_raw.p, sc.k64_a.p, 32);
-    sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.perm_f.p, tr.perm_uf.p, n, ubits, st);
-    k_make_keys<<<nblocks(n), TPB, 0, st>>>(n, 3, sc.du_row.p, sc.di_row.p, tr.user_raw.p, tr.item_raw.p, sc.k64_a.p, 32);
-    sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.perm_f.p, tr.perm_if.p, n, ibits, st);
-    k_segment_ptr<<<nblocks((int64_t)I + 1), TPB, 0, st>>>(n, sc.k64_b.p, 0, tr.I, tr.i_ptr.p);
+    k_copy_keys_u32<<<nblocks(n), TPB, 0, st>>>(n, sc.du_row.p, sc.k32_a.p);
+    sort_pairs_u32_u32(sc.sort, sc.k32_a.p, sc.k32_b.p, sc.perm_f.p, tr.perm_uf.p, n, ubits, st);
+    k_copy_keys_u32<<<nblocks(n), TPB, 0, st>>>(n, sc.di_row.p, sc.k32_a.p);
+    sort_pairs_u32_u32(sc.sort, sc.k32_a.p, sc.k32_b.p, sc.perm_f.p, tr.perm_if.p, n, ibits, st);
+    k_segment_ptr_u32<<<nblocks((int64_t)I + 1), TPB, 0, st>>>(n, sc.k32_b.p, tr.I, tr.i_ptr.p);
     KN_HIP(hipGetLastError());
     if (n > 4) {  // a Map of <= 4 entries (Map1..Map4) iterates in insertion = file order (N4)
         tr.perm_uh.alloc(n); tr.perm_ih.alloc(n);

@@ -21,6 +21,17 @@ void sort_pairs_u64_u32(SortWorkspace& ws, const uint64_t* kin, uint64_t* kout, 
     KN_HIP(rocprim::radix_sort_pairs(ws.tmp.p, bytes, kin, kout, vin, vout, n, 0, (unsigned)end_bit, st));
 }
 
+void sort_pairs_u32_u32(SortWorkspace& ws, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout, size_t n,
+                        int end_bit, hipStream_t st) {
+    if (n == 0) return;
+    if (end_bit < 1) end_bit = 1;
+    if (end_bit > 32) end_bit = 32;
+    size_t bytes = 0;
+    KN_HIP(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, 0, (unsigned)end_bit, st));
+    ws.tmp.ensure(bytes);
+    KN_HIP(rocprim::radix_sort_pairs(ws.tmp.p, bytes, kin, kout, vin, vout, n, 0, (unsigned)end_bit, st));
+}
+
 void sort_keys_u32(SortWorkspace& ws, const uint32_t* kin, uint32_t* kout, size_t n, hipStream_t st) {
     if (n == 0) return;
     size_t bytes = 0;
@@ -32,8 +43,8 @@ void sort_keys_u32(SortWorkspace& ws, const uint32_t* kin, uint32_t* kout, size_
 size_t unique_u32(SortWorkspace& ws, const uint32_t* sorted_in, uint32_t* out, size_t n, hipStream_t st) {
     if (n == 0) return 0;
     size_t bytes = 0;
-    DArr<size_t> d_count;
-    d_count.alloc(1);
+    DArr<size_t>& d_count = ws.count;
+    d_count.ensure(1);
     KN_HIP(rocprim::unique(nullptr, bytes, sorted_in, out, d_count.p, n, rocprim::equal_to<uint32_t>(), st));
     ws.tmp.ensure(bytes);
     KN_HIP(rocprim::unique(ws.tmp.p, bytes, sorted_in, out, d_count.p, n, rocprim::equal_to<uint32_t>(), st));
