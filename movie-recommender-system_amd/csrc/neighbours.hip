@@ -110,7 +110,10 @@ void launch_jaccard_pair(const Train& tr, int32_t u, int32_t v, double* d_out, h
 namespace knncf {
 
 // copy of each built neighbour list sorted by dense neighbour id (prediction probes the item's rater
-// list, which is sorted the same way): one workgroup per row, LDS bitonic sort
+// list, which is sorted the same way): one workgroup per row, LDS bitonic sort of (id, position) packed in 64 bits;
+// the similarities are gathered by position at the end.  Pair t of a stage belongs to the 128-element block t / 64,
+// and a wave owns whole blocks: stages of stride <= 64 stay inside one wave's blocks and need no workgroup barrier
+// (42 of the 45 stages at k = 300).
 __global__ void __launch_bounds__(256) k_sort_neighbors_by_id(int32_t n_rows, const int32_t* __restrict__ row_user, int32_t kcap,
                                                               const int32_t* __restrict__ nbr_idx, const double* __restrict__ nbr_sim,
                                                               const int32_t* __restrict__ nbr_cnt, int32_t* __restrict__ uidx,
@@ -120,40 +123,42 @@ __global__ void __launch_bounds__(256) k_sort_neighbors_by_id(int32_t n_rows, co
     if (r >= n_rows) return;
     const int32_t u = row_user[r];
     const int32_t cnt = nbr_cnt[u];
-    int32_t m = 1;
+    int32_t m = 128;  // (whole blocks of 128: the wave-local stages assume them)
     while (m < cnt) m <<= 1;
-    double* ss = reinterpret_cast<double*>(smem);
-    int32_t* si = reinterpret_cast<int32_t*>(ss + m);
+    unsigned long long* key = reinterpret_cast<unsigned long long*>(smem);
     const int64_t base = (int64_t)u * kcap;
-    for (int32_t j = threadIdx.x; j < m; j += 256) {
-        si[j] = j < cnt ? nbr_idx[base + j] : 0x7fffffff;
-        ss[j] = j < cnt ? nbr_sim[base + j] : 0.0;
-    }
+    for (int32_t j = threadIdx.x; j < m; j += 256)
+        key[j] = j < cnt ? ((unsigned long long)(uint32_t)nbr_idx[base + j] << 32) | (uint32_t)j : ~0ull;
     __syncthreads();
     for (int32_t size = 2; size <= m; size <<= 1)
         for (int32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            const bool across = stride > 64;  // partners in different blocks: other waves' elements
+            if (across) __syncthreads();
             for (int32_t t = threadIdx.x; t < (m >> 1); t += 256) {
                 const int32_t lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
                 const bool up = ((lo & size) == 0);
-                const int32_t ia = si[lo], ib = si[hi];
-                if ((ia < ib) != up) {
-                    si[lo] = ib; si[hi] = ia;
-                    const double x = ss[lo]; ss[lo] = ss[hi]; ss[hi] = x;
-                }
+                const unsigned long long ka = key[lo], kb = key[hi];
+                if ((ka < kb) != up) { key[lo] = kb; key[hi] = ka; }
             }
-            __syncthreads();
+            if (across) __syncthreads();
+            else {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
         }
+    __syncthreads();
     for (int32_t j = threadIdx.x; j < cnt; j += 256) {
-        uidx[base + j] = si[j];
-        usim[base + j] = ss[j];
+        const unsigned long long k = key[j];
+        uidx[base + j] = (int32_t)(k >> 32);
+        usim[base + j] = nbr_sim[base + (uint32_t)k];
     }
 }
 
 void launch_sort_neighbors(NeighborTable& nt, int32_t n_rows, const int32_t* d_row_user, hipStream_t st) {
     if (n_rows <= 0 || nt.kcap <= 0) return;
-    int32_t m = 1;
+    int32_t m = 128;
     while (m < nt.kcap) m <<= 1;
-    const size_t smem = (size_t)m * 12;
+    const size_t smem = (size_t)m * 8;
     k_sort_neighbors_by_id<<<n_rows, 256, smem, st>>>(n_rows, d_row_user, nt.kcap, nt.idx.p, nt.sim.p, nt.cnt.p, nt.uidx.p, nt.usim.p);
     KN_HIP(hipGetLastError());
 }
