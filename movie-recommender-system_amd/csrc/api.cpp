@@ -16,6 +16,7 @@ namespace knncf {
 // small kernels of the orchestrator (neighbours.hip)
 void launch_first_rows(int64_t n, const int32_t* d_du, const int32_t* d_di, int32_t own_lo, int32_t own_hi,
                        uint32_t* d_first, hipStream_t st);
+void launch_length_keys(int32_t count, const int32_t* d_list, const int64_t* d_u_ptr, uint64_t* d_key, hipStream_t st);
 void launch_collect_new(int32_t U, const uint32_t* d_first, int64_t* d_seq, int64_t epoch, int32_t* d_list,
                         int32_t* d_count, hipStream_t st);
 void launch_fallback_keys(int32_t U, const double* d_exact, uint64_t* d_keys, uint32_t* d_vals, hipStream_t st);
@@ -260,6 +261,16 @@ void build_neighbors(knncf_handle* h, int32_t count) {
     KN_REQUIRE(h->cfg.similarity == KNNCF_SIM_COSINE, KNNCF_E_UNSUPPORTED,
                "kNN neighbourhoods are built for the adjusted-cosine similarity only");
     hipStream_t st = h->stream;
+    if (count > 256) {
+        // longest rows first (LPT): one workgroup per row in select and re-rank, and the row lengths are heavy-tailed
+        // (ml-25m shape: mean 123 ratings, maximum 7485) — a long row dispatched last holds the launch open alone.
+        // The order of the list carries no meaning (the users' build sequence numbers are already assigned).
+        PrepScratch& sc = h->prep;
+        sc.k64_a.ensure(count); sc.k64_b.ensure(count); sc.v32_b.ensure(count);
+        launch_length_keys(count, h->build_list.p, tr.u_ptr.p, sc.k64_a.p, st);
+        sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, reinterpret_cast<const uint32_t*>(h->build_list.p), sc.v32_b.p, count, 32, st);
+        KN_HIP(hipMemcpyAsync(h->build_list.p, sc.v32_b.p, (size_t)count * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    }
     const bool fp16 = (h->cfg.flags & KNNCF_FLAG_BF16_FILTER) == 0;
     const bool s_fp16 = (h->cfg.flags & KNNCF_FLAG_F32_PANEL) == 0;  // similarity panel stored as fp16 (half the HBM traffic)
     h->U_pad = round_up(tr.U, 256);
