@@ -173,7 +173,7 @@ def main():
         # separate runs, corrected as MI355X_MICROARCH.md prescribes: see profiles/README.md); null for any other setup —
         # counters cannot be collected from inside this process
         pmc = {}
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01n_pmc_traffic_syn25m_1gpu.json")
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01p_pmc_traffic_syn25m_1gpu.json")
         if world == 1 and split.name == "syn-25m" and args.engine_flags == 0 and args.head_items == 0 and args.k == 300 and os.path.exists(pmc_path):
             with open(pmc_path) as f:
                 pmc = json.load(f)["kernels"]
@@ -187,7 +187,7 @@ def main():
                  "algorithmic_work": note, "algorithmic_per_launch": work / launches}
             if key in pmc:
                 r["traffic"] = pmc[key]["traffic_bytes_per_launch"]
-                r["traffic_source"] = "profiles/r01n_pmc_traffic_syn25m_1gpu.json (2 x FETCH_SIZE + WRITE_SIZE, bytes per launch)"
+                r["traffic_source"] = "profiles/r01p_pmc_traffic_syn25m_1gpu.json (2 x FETCH_SIZE + WRITE_SIZE, bytes per launch)"
             return r
 
         kernels = {
