@@ -88,6 +88,7 @@ struct PrepScratch {
     DArr<uint32_t> perm_f;
     DArr<uint32_t> status;  // [4] device status words
     DArr<double> dsum;      // small reduction scratch
+    DArr<uint4> rec;        // [2 n] (preprocessed rating, deviation | user, file row) records: one 32-byte gather per entry
     // side streams for the three independent item folds of prep_commit (created on first use)
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
