@@ -9,11 +9,18 @@ MovieLens here or on the GPU box), seeded, ml-25m-shaped; they sit in HBM before
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     — the similarity GEMM (dominant kernel) against the dense bf16 MFMA peak,
-                 achieved = ALGORITHMIC flops (U (U-1) I_c) / measured kernel time
-  cpu_baseline — the fp64 CPU restatement (oracle, 1 thread like the reference's local[1]) timed on
-                 a bounded sample of the same workload on this host.
+Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
+  roofline      — the DOMINANT kernel of this run by summed launch time (k_tail_select at the ml-25m shape), priced on
+                  its COMPULSORY HBM bytes (the similarity panel it reads + one pass over the 4-byte tail entries) against
+                  the 8 TB/s HBM peak; the same object carries the kernel's other roofs (`other_roofs`: LDS-atomic
+                  updates/s against the measured 9.6 updates/clk/CU of scripts/microbench/lds_atomic_rate.hip) and says
+                  which one binds (`binding`).  Every frac can be recomputed from the printed definitions + profiles/.
+  roofline_all  — the same for the GEMM (MFMA; frac on SURVEY 8d's each-unordered-pair-once flops, `executed_tflops`
+                  beside it), the re-rank and the prediction kernel.
+  cpu_baseline  — the fp64 CPU restatement (oracle, 1 thread like the reference's local[1]) timed on a bounded sample
+                  of the same workload on this host; cpu_baseline_all_cores — the oracle's threaded bulk form on all
+                  host cores (cores stated), same bounded-sample protocol.
+  step_ms       — mean / population sigma / min / max over the timed steps (shared/predictions.scala:18-25).
 """
 import argparse
 import importlib
@@ -28,6 +35,10 @@ if ROOT not in sys.path:
 PKG = "movie-recommender-system_amd"
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16/fp16
 HBM_PEAK_TBPS = 8.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# scripts/microbench/lds_atomic_rate.hip on MI355X: 9.6 random-address integer LDS lane-updates per clock per CU
+LDS_ATOMIC_UPDATES_PER_CLK_PER_CU = 9.6
+CUS, CLOCK_GHZ = 256, 2.4
+PMC_PROFILE = "r02_pmc_traffic_syn25m_1gpu.json"  # profiles/: the PMC passes of this exact workload (scripts/profile_round.sh)
 
 
 def log(*a):
@@ -46,7 +57,7 @@ def make_workload(name, synth):
 
 
 def cpu_baseline(split, k, budget_s, n_test_total):
-    """Oracle (C restatement, fp64, reference order, single thread) on the first test users."""
+    """(1-thread literal oracle, all-cores bulk oracle) on the first test users, each for about budget_s seconds."""
     import numpy as np
 
     from oracle import knncf_oracle as O
@@ -56,10 +67,12 @@ def cpu_baseline(split, k, budget_s, n_test_total):
     t0 = time.perf_counter()
     model = O.Model(tr.users, tr.items, tr.ratings)
     t_fit = time.perf_counter() - t0
-    pipe = model.pipeline(O.SIM_COSINE, k)
-    # first-appearance order of test users, grow the sample until the budget is spent
+    # first-appearance order of test users
     _, first = np.unique(te.users, return_index=True)
     order = te.users[np.sort(first)]
+
+    # (1) the literal per-pair closures on one thread (the reference forces local[1]); grow the sample until the budget is spent
+    pipe = model.pipeline(O.SIM_COSINE, k)
     done_preds, t_pred, n_users = 0, 0.0, 0
     chunk = 4
     while t_pred < budget_s and n_users < len(order):
@@ -73,13 +86,39 @@ def cpu_baseline(split, k, budget_s, n_test_total):
         chunk = min(chunk * 2, 64)
     # whole-job rate = sample predictions / (their neighbour+predict time + their share of the fit)
     share = t_fit * done_preds / max(1, n_test_total)
-    value = done_preds / (t_pred + share)
-    return {
-        "value": value, "unit": "predictions/s", "cores": 1, "kind": "port",
+    one = {
+        "value": done_preds / (t_pred + share), "unit": "predictions/s", "cores": 1, "kind": "port",
         "sample": (f"oracle (C fp64 restatement of shared/predictions.scala, reference is single-threaded local[1]): "
                    f"first {n_users} test users = {done_preds} predictions in {t_pred:.1f} s after a {t_fit:.1f} s fit "
                    f"(fit amortised over all {n_test_total} predictions); host has {os.cpu_count()} cores"),
     }
+    # (2) the same closures in the oracle's bulk form (row-wise accumulation, one user per thread) on every core this
+    # process may use: neighbour lists of the sample users, then their test rows
+    cores = O.host_threads()
+    all_cores = None
+    try:
+        done_preds, t_used, n_users = 0, 0.0, 0
+        chunk = 256 * cores
+        while t_used < budget_s and n_users < len(order):
+            users = order[n_users:n_users + chunk]
+            mask = np.isin(te.users, users)
+            t1 = time.perf_counter()
+            table = model.knn_table(k, users=users, threads=cores)
+            table.mae(te.users[mask], te.items[mask], te.ratings[mask])
+            t_used += time.perf_counter() - t1
+            del table
+            done_preds += int(mask.sum())
+            n_users += len(users)
+        share = t_fit * done_preds / max(1, n_test_total)
+        all_cores = {
+            "value": done_preds / (t_used + share), "unit": "predictions/s", "cores": cores, "kind": "port",
+            "sample": (f"oracle bulk form (OpenMP, one user per thread; tests/test_oracle_bulk.py pins it bit for bit to the "
+                       f"literal closures): first {n_users} test users = {done_preds} predictions in {t_used:.1f} s on {cores} "
+                       f"threads, same amortised single-threaded {t_fit:.1f} s fit"),
+        }
+    except O.OracleError:
+        pass  # a user with <= 4 ratings: the bulk form refuses (memo-history dependent)
+    return one, all_cores
 
 
 def main():
@@ -91,7 +130,9 @@ def main():
     ap.add_argument("--k", type=int, default=300)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bf16-leg", action="store_true", help="skip the extra (untimed) bf16-operand steps reported beside the fp16 default")
     ap.add_argument("--head-items", type=int, default=0, help="dense head width of the hybrid similarity (0 = cost model)")
+    ap.add_argument("--workspace-bytes", type=int, default=0, help="cap of the similarity-panel workspace (0 = auto); small values = small row blocks")
     ap.add_argument("--engine-flags", type=int, default=0, help="KNNCF_FLAG_* bits (1 verify bound, 2 overlap, 4 bf16 filter operands instead of fp16)")
     args = ap.parse_args()
 
@@ -134,7 +175,7 @@ def main():
     torch.cuda.synchronize()
 
     eng = kn.Engine(k=args.k, similarity=kn.SIM_COSINE, device=local_rank, shard_rank=rank, shard_count=world,
-                    head_items=args.head_items, flags=args.engine_flags)
+                    head_items=args.head_items, flags=args.engine_flags, workspace_bytes=args.workspace_bytes)
     model = sharded.ShardedKnn(sharded.DeviceEngineAdapter(eng, device), dist, rank, world)
 
     def step():
@@ -152,14 +193,17 @@ def main():
     eng.reset_timings()
     barrier()
     t_start = time.perf_counter()
+    step_end = []
     for _ in range(args.steps):
-        mae, n_pred = step()
+        mae, n_pred = step()          # (returns after the device work of the step: the sums come back to the host)
+        step_end.append(time.perf_counter())
     barrier()
     elapsed = time.perf_counter() - t_start
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    step_ms = np.diff(np.array([t_start] + step_end)) * 1e3
     tm = eng.timings()
 
     if rank == 0:
@@ -169,12 +213,13 @@ def main():
         launches = max(1, tm["gemm_launches"])  # every per-row-block kernel is launched once per GEMM launch
         k = args.k
 
-        # HBM traffic per launch from the committed PMC passes of this workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-        # separate runs, corrected as MI355X_MICROARCH.md prescribes: see profiles/README.md); null for any other setup —
-        # counters cannot be collected from inside this process
+        # Cache/HBM-side traffic per launch from the committed PMC passes of this workload (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE in separate runs, corrected as MI355X_MICROARCH.md prescribes: profiles/README.md); null for any other
+        # setup — counters cannot be collected from inside this process.  (FETCH_SIZE also counts Infinity-Cache hits: it
+        # is an upper bound of the HBM bytes.)
         pmc = {}
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01p_pmc_traffic_syn25m_1gpu.json")
-        if world == 1 and split.name == "syn-25m" and args.engine_flags == 0 and args.head_items == 0 and args.k == 300 and os.path.exists(pmc_path):
+        pmc_path = os.path.join(ROOT, "profiles", PMC_PROFILE)
+        if world == 1 and split.name == "syn-25m" and args.engine_flags == 0 and args.head_items == 0 and args.workspace_bytes == 0 and args.k == 300 and os.path.exists(pmc_path):
             with open(pmc_path) as f:
                 pmc = json.load(f)["kernels"]
 
@@ -187,24 +232,47 @@ def main():
                  "algorithmic_work": note, "algorithmic_per_launch": work / launches}
             if key in pmc:
                 r["traffic"] = pmc[key]["traffic_bytes_per_launch"]
-                r["traffic_source"] = "profiles/r01p_pmc_traffic_syn25m_1gpu.json (2 x FETCH_SIZE + WRITE_SIZE, bytes per launch)"
+                r["traffic_source"] = f"profiles/{PMC_PROFILE} (2 x FETCH_SIZE + WRITE_SIZE, bytes per launch; includes Infinity-Cache hits)"
             return r
 
+        n_train = len(tr)
         kernels = {
+            # each UNORDERED pair once x 2 flops x the columns the dense part contracts (head_items); the kernel
+            # executes the full square (both orders of every pair, padded tiles): executed_tflops beside it
             "k_gemm_nt_bf16": roof("k_gemm_nt_bf16 (user x user similarity, dense head, MFMA)", "mfma", tm["gemm_ms"],
-                                   tm["gemm_flops_algorithmic"], MFMA_BF16_DENSE_PEAK_TFLOPS, "TFLOP/s",
-                                   "2 * rows * (U-1) * head_items flops per launch", key="k_gemm_nt_bf16"),
+                                   0.5 * tm["gemm_flops_algorithmic"], MFMA_BF16_DENSE_PEAK_TFLOPS, "TFLOP/s",
+                                   "rows * (U-1) * head_items flops per launch = each unordered (row, user) pair once x 2 flops x head_items "
+                                   "(SURVEY 8d with I_c -> the dense head; the sparse tail is k_tail_select's work)", key="k_gemm_nt_bf16"),
+            # compulsory HBM bytes: the similarity panel is read once, the 4-byte tail entries once per launch (their ~450
+            # re-reads per launch are served by L2 / Infinity Cache and are priced on the LDS-atomic roof instead)
             "k_tail_select": roof("k_tail_select (sparse tail + histogram select)", "hbm", tm["select_ms"],
-                                  tm["select_row_bytes"] + 4.0 * tm["tail_pair_updates"], HBM_PEAK_TBPS, "TB/s",
-                                  "panel entry size (2 B fp16 / 4 B fp32) * rows * U, read once + 4 B per tail pair product (packed column | Q0.16 value)",
-                                  key="k_tail_select"),
+                                  tm["select_row_bytes"] + 4.0 * n_train * launches, HBM_PEAK_TBPS, "TB/s",
+                                  "compulsory bytes: panel entry size (2 B fp16 / 4 B fp32) * rows * U read once + 4 B * train ratings "
+                                  "(one pass over the tail entries) per launch", key="k_tail_select"),
             "k_rerank": roof("k_rerank (exact fp64 re-rank + top-k)", "hbm", tm["rerank_ms"], tm["rerank_row_bytes"],
-                             HBM_PEAK_TBPS, "TB/s", "12 B * ratings of every shortlisted candidate", key="k_rerank"),
+                             HBM_PEAK_TBPS, "TB/s", "12 B * ratings of every shortlisted candidate (no reuse assumed; the rows are "
+                             "re-read from L2 / Infinity Cache, so this is cache-level, not compulsory HBM, traffic)", key="k_rerank"),
             "k_predict_knn": roof("k_predict_knn_items (weighted-sum prediction + MAE; the stage also holds the id lookup and the row sort)",
                                   "hbm", tm["predict_ms"], 12.0 * k * n_test * steps, HBM_PEAK_TBPS, "TB/s",
                                   "12 * k B per prediction (SURVEY 8d)", launches=steps, key="k_predict_knn"),
         }
-        kernels["k_gemm_nt_bf16"]["executed_tflops"] = (tm["gemm_flops_executed"] / launches) / (tm["gemm_ms"] / launches / 1e3) / 1e12 if tm["gemm_ms"] > 0 else 0.0
+        g = kernels["k_gemm_nt_bf16"]
+        g["executed_tflops"] = (tm["gemm_flops_executed"] / launches) / (tm["gemm_ms"] / launches / 1e3) / 1e12 if tm["gemm_ms"] > 0 else 0.0
+        g["executed_frac"] = g["executed_tflops"] / MFMA_BF16_DENSE_PEAK_TFLOPS
+        # the tail's other roof: integer LDS atomics (one per tail pair product)
+        ts = kernels["k_tail_select"]
+        lds_peak = LDS_ATOMIC_UPDATES_PER_CLK_PER_CU * CUS * CLOCK_GHZ * 1e9
+        upd_per_s = tm["tail_pair_updates"] / (tm["select_ms"] / 1e3) if tm["select_ms"] > 0 else 0.0
+        ts["other_roofs"] = {
+            "lds_atomic": {"achieved": upd_per_s / 1e12, "peak": lds_peak / 1e12, "unit": "T lane-updates/s", "frac": upd_per_s / lds_peak,
+                           "definition": f"tail pair products per step ({tm['tail_pair_updates'] / steps:.3e}: sum over tail items of raters-in-rows x raters) "
+                                         f"/ kernel time; peak = {LDS_ATOMIC_UPDATES_PER_CLK_PER_CU} updates/clk/CU (scripts/microbench/lds_atomic_rate.hip) x {CUS} CUs x {CLOCK_GHZ} GHz"},
+            "cache_level_bytes": {"achieved": (tm["select_row_bytes"] + 4.0 * tm["tail_pair_updates"]) / (tm["select_ms"] / 1e3) / 1e12 if tm["select_ms"] > 0 else 0.0,
+                                  "unit": "TB/s", "definition": "panel bytes + 4 B per tail pair product (L2 / Infinity-Cache re-reads of the rater lists; NOT HBM bytes)"},
+        }
+        ts["binding"] = ("neither roof: the kernel is VALU-issue bound (profiles/*_pmc_traffic_*.json, SQ pass: ~70 % VALU issue "
+                         "utilisation, ~16 VALU instructions per 64-entry tail piece); HBM frac on compulsory bytes and the "
+                         "LDS-atomic frac are both reported")
         stage_of = {"k_gemm_nt_bf16": "gemm_ms", "k_tail_select": "select_ms", "k_rerank": "rerank_ms", "k_predict_knn": "predict_ms"}
         dominant = max(stage_of, key=lambda n: tm[stage_of[n]])
         out = {
@@ -213,6 +281,8 @@ def main():
             "unit": "predictions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            "step_ms": {"mean": float(step_ms.mean()), "sigma": float(step_ms.std()), "min": float(step_ms.min()), "max": float(step_ms.max()),
+                        "note": "rank 0's wall time per step; population sigma as shared/predictions.scala:19-25"},
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -229,9 +299,37 @@ def main():
             "shortlist_mean": tm["shortlist_total"] / max(1, steps * eng.num_users),
             "fallback_rows_per_step": tm["fallback_rows"] / steps,
             "hybrid": {"head_items": tm["head_items"], "tail_pair_updates_per_step": tm["tail_pair_updates"] / steps},
+            # the only throughput the reference publishes (knn-100k.json:53-58: 26.2 s for 20 000 predictions at
+            # ml-100k, k = 300, Spark local[1]); another data set and unknown hardware, so vs_baseline stays null
+            "reference_published": {"value": 763.0, "unit": "predictions/s", "workload": "ml-100k u2 kNN k=300 (knn-100k.json:53-58)",
+                                    "hardware": "unstated"},
         }
+        if world == 1 and not args.no_bf16_leg and not (args.engine_flags & 4):
+            # north_star says bf16 operands; the default is fp16 (same MFMA rate, 8x narrower error band, identical
+            # results).  The bf16 number of the same build, outside the timed region:
+            eb = kn.Engine(k=args.k, similarity=kn.SIM_COSINE, device=local_rank, head_items=args.head_items,
+                           flags=args.engine_flags | kn.FLAG_BF16_FILTER)
+            mb = sharded.ShardedKnn(sharded.DeviceEngineAdapter(eb, device), None, 0, 1)
+            mb.fit(*d_tr)
+            mb.mae(kn.PRED_KNN, *d_te)
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            nb = max(1, min(3, args.steps))
+            for _ in range(nb):
+                mb.fit(*d_tr)
+                mae_b, _ = mb.mae(kn.PRED_KNN, *d_te)
+            torch.cuda.synchronize()
+            dtb = (time.perf_counter() - tb) / nb
+            out["bf16_filter"] = {"ms_per_step": dtb * 1e3, "value": n_test / dtb, "unit": "predictions/s", "steps": nb,
+                                  "mae": mae_b, "shortlist_mean": eb.timings()["shortlist_total"] / max(1, (nb + 1) * eb.num_users),
+                                  "note": "KNNCF_FLAG_BF16_FILTER (bf16 GEMM operands as north_star words it): same neighbours and MAE, "
+                                          "wider error band -> longer shortlists -> more re-rank work"}
+            eb.close()
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(split, args.k, args.cpu_baseline_seconds, n_test)
+            one, all_cores = cpu_baseline(split, args.k, args.cpu_baseline_seconds, n_test)
+            out["cpu_baseline"] = one
+            if all_cores:
+                out["cpu_baseline_all_cores"] = all_cores
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -13,8 +13,14 @@
  * Conventions: every function returns a status (0 ok, negative error; text via
  * knncf_last_error).  Ids are the RAW user/item ids of the rating files, in
  * and out.  Host-pointer and device-pointer variants exist for the bulk calls;
- * "_device" pointers must live on the handle's HIP device.  A handle is not
- * thread-safe.  The library owns all device memory it allocates.  There is no
+ * "_device" pointers must live on the handle's HIP device, and their contents
+ * must be COMPLETE when the call is made: the engine works on private
+ * non-blocking HIP streams and cannot order itself after the caller's
+ * producer stream (synchronise that stream, or wait on its event, first);
+ * results written to caller-provided device buffers are complete on return.
+ * A handle is not thread-safe; different handles may be used from different
+ * threads and on different devices (per-device kernel state is keyed by device
+ * ordinal); the calling thread's current device is restored on return.  The library owns all device memory it allocates.  There is no
  * CPU fallback: without a usable gfx950 device knncf_create fails.
  */
 #ifndef KNNCF_H
@@ -130,6 +136,11 @@ int knncf_knn_similarity(knncf_handle* h, int32_t u, int32_t v, double* out);
 /* getNeighbors(train, k, sim)(u): ids and similarities in reference order :603-616 */
 int knncf_neighbors(knncf_handle* h, int32_t u, int32_t cap, int32_t* ids, double* sims,
                     int32_t* count);
+/* getNeighbors for users[0..n) at once ("as if called in this order"): row j of ids / sims ([n * cap]) receives
+ * min(counts[j], cap) entries.  Neighbourhoods that do not exist yet are built in ONE batch on the device — the bulk
+ * door for exporting or verifying whole neighbour tables (knncf_neighbors costs a device round trip per user). */
+int knncf_neighbors_batch(knncf_handle* h, const int32_t* users, int64_t n, int32_t cap, int32_t* ids,
+                          double* sims, int32_t* counts);
 int knncf_predict(knncf_handle* h, int predictor, int32_t user, int32_t item, double* out);
 
 /* recommendations(train, predictor)(user, n) shared/predictions.scala:651-674 (called by
@@ -186,6 +197,21 @@ typedef struct knncf_ratings {
 } knncf_ratings;
 int knncf_load_file(const char* path, const char* separator, int threads, knncf_ratings* out, char* err, int err_cap);
 void knncf_free_ratings(knncf_ratings* r);
+
+/* The Recommender's personal-ratings file, recommend/Recommender.scala:40-54 ("id,title,rating" CSV): every row's
+ * (id, title) in file order — the header row as (0, "header") — and the rows with a non-zero rating as ratings of
+ * `user` (the reference uses 944), ready to be appended to the training rows (`data.union(personal)` :68).  Rows with
+ * an empty rating column are unrated; a non-numeric id / rating fails loudly (the reference throws).  Release with
+ * knncf_free_personal. */
+typedef struct knncf_personal {
+    int64_t n_rows;
+    int32_t* row_ids;      /* [n_rows] */
+    char** row_names;      /* [n_rows] NUL-terminated, owned by the struct */
+    char* name_storage;
+    knncf_ratings ratings; /* the non-zero ratings, file order */
+} knncf_personal;
+int knncf_load_personal(const char* path, int32_t user, knncf_personal* out, char* err, int err_cap);
+void knncf_free_personal(knncf_personal* p);
 
 /* Checkpoint / resume of the expensive part of a fit: the U x k neighbour table (ids, fp64 similarities, build
  * sequence numbers).  save: every neighbourhood built so far.  load: the handle must be fitted on the same training

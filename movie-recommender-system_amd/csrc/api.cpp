@@ -106,8 +106,9 @@ struct Stage {  // RAII: times a stage of device work with HIP events on the str
     }
 };
 
+// end of every entry point: the engine's streams are drained (results in caller-provided device buffers are complete on
+// return, include/knncf.h) and the stage timers of the call are read
 void resolve_timers(knncf_handle* h) {
-    if (h->pending.empty()) return;
     (void)hipStreamSynchronize(h->stream);
     (void)hipStreamSynchronize(h->stream2);
     for (auto& t : h->pending) {
@@ -122,8 +123,17 @@ void resolve_timers(knncf_handle* h) {
 template <class F>
 int guarded(knncf_handle* h, F&& f) {
     if (!h) return KNNCF_E_INVALID;
+    // the calling thread's current device is restored on every path (a JVM thread may drive several handles)
+    struct DeviceGuard {
+        int prev = -1;
+        ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    } guard;
     try {
-        KN_HIP(hipSetDevice(h->cfg.device));
+        int cur = -1;
+        if (hipGetDevice(&cur) == hipSuccess && cur != h->cfg.device) {
+            guard.prev = cur;
+            KN_HIP(hipSetDevice(h->cfg.device));
+        }
         f();
         resolve_timers(h);
         return KNNCF_OK;
@@ -910,6 +920,90 @@ int knncf_neighbors(knncf_handle* h, int32_t u, int32_t cap, int32_t* ids, doubl
         for (size_t j = 0; j < di.size() && (int32_t)j < cap; ++j) { ids[j] = h->h_uid[di[j]]; sims[j] = ds[j]; }
         *count = (int32_t)di.size();
     });
+}
+
+// getNeighbors(train, k, sim) for many users: the missing neighbourhoods are built in ONE batch (memo history: as if the
+// closure had been called for users[0], users[1], ... in this order), then the lists are copied out
+static void do_neighbors_batch(knncf_handle* h, const int32_t* users, int64_t n, int32_t cap, int32_t* ids, double* sims, int32_t* counts) {
+    require_fitted(h);
+    KN_REQUIRE(n >= 0 && cap >= 0 && (n == 0 || (users && counts)) && (n == 0 || cap == 0 || (ids && sims)), KNNCF_E_INVALID, "bad arguments");
+    KN_REQUIRE(h->cfg.similarity == KNNCF_SIM_COSINE, KNNCF_E_UNSUPPORTED, "neighbourhoods: adjusted cosine only");
+    if (n == 0) return;
+    Train& tr = h->tr;
+    NeighborTable& nt = h->nt;
+    hipStream_t st = h->stream;
+    load_host_ids(h);
+    std::vector<int32_t> du((size_t)n);
+    for (int64_t j = 0; j < n; ++j) {
+        du[j] = dense_lookup(h->h_ukeys.data(), tr.U, users[j]);
+        KN_REQUIRE(du[j] < 0 || (du[j] >= tr.own_lo && du[j] < tr.own_hi), KNNCF_E_INVALID, "user belongs to another shard");
+    }
+    const bool have_lists = tr.U >= 2 && nt.kcap > 0;
+    if (have_lists) {
+        std::vector<int64_t> seq((size_t)tr.U);
+        KN_HIP(hipMemcpyAsync(seq.data(), nt.seq.p, seq.size() * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        KN_HIP(hipStreamSynchronize(st));
+        std::vector<int32_t> fresh;
+        for (int64_t j = 0; j < n; ++j)
+            if (du[j] >= 0 && seq[du[j]] < 0) {
+                seq[du[j]] = (h->epoch << 32) | (int64_t)std::min<int64_t>(j, 0xffffffffll);
+                fresh.push_back(du[j]);
+            }
+        if (!fresh.empty()) {
+            h->epoch += 1;
+            h->build_list.ensure(tr.U);
+            KN_HIP(hipMemcpyAsync(nt.seq.p, seq.data(), seq.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
+            KN_HIP(hipMemcpyAsync(h->build_list.p, fresh.data(), fresh.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            KN_HIP(hipStreamSynchronize(st));
+            build_neighbors(h, (int32_t)fresh.size());
+        }
+    }
+    const size_t kc = (size_t)std::max(nt.kcap, 1);
+    std::vector<int32_t> h_cnt, h_idx;
+    std::vector<double> h_sim;
+    const bool whole = have_lists && n > 1024;  // one big copy instead of 2 n small ones
+    if (have_lists) {
+        h_cnt.resize(tr.U);
+        KN_HIP(hipMemcpyAsync(h_cnt.data(), nt.cnt.p, h_cnt.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        if (whole) {
+            h_idx.resize((size_t)tr.U * kc);
+            h_sim.resize((size_t)tr.U * kc);
+            KN_HIP(hipMemcpyAsync(h_idx.data(), nt.idx.p, h_idx.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            KN_HIP(hipMemcpyAsync(h_sim.data(), nt.sim.p, h_sim.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        }
+        KN_HIP(hipStreamSynchronize(st));
+    }
+    std::vector<int32_t> row_idx(kc);
+    std::vector<double> row_sim(kc);
+    for (int64_t j = 0; j < n; ++j) {
+        int32_t* oi = ids + (size_t)j * cap;
+        double* os = sims + (size_t)j * cap;
+        if (du[j] < 0) {  // user absent from train: every similarity is 0.0, ties keep Set order (N3)
+            const int32_t c = std::min(nt.k, tr.U);
+            for (int32_t q = 0; q < c && q < cap; ++q) { oi[q] = h->h_uid[q]; os[q] = 0.0; }
+            counts[j] = c;
+            continue;
+        }
+        const int32_t c = have_lists ? h_cnt[du[j]] : 0;
+        const int32_t* src_i = nullptr;
+        const double* src_s = nullptr;
+        if (whole) {
+            src_i = h_idx.data() + (size_t)du[j] * kc;
+            src_s = h_sim.data() + (size_t)du[j] * kc;
+        } else if (c > 0) {
+            KN_HIP(hipMemcpyAsync(row_idx.data(), nt.idx.p + (size_t)du[j] * kc, c * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            KN_HIP(hipMemcpyAsync(row_sim.data(), nt.sim.p + (size_t)du[j] * kc, c * sizeof(double), hipMemcpyDeviceToHost, st));
+            KN_HIP(hipStreamSynchronize(st));
+            src_i = row_idx.data();
+            src_s = row_sim.data();
+        }
+        for (int32_t q = 0; q < c && q < cap; ++q) { oi[q] = h->h_uid[src_i[q]]; os[q] = src_s[q]; }
+        counts[j] = c;
+    }
+}
+
+int knncf_neighbors_batch(knncf_handle* h, const int32_t* users, int64_t n, int32_t cap, int32_t* ids, double* sims, int32_t* counts) {
+    return guarded(h, [&] { do_neighbors_batch(h, users, n, cap, ids, sims, counts); });
 }
 
 int knncf_knn_similarity(knncf_handle* h, int32_t u, int32_t v, double* out) {

@@ -335,40 +335,19 @@ Json run_distributed(const Args& a, const Ratings& train, const Ratings& test) {
     return out;
 }
 
-// recommend/Recommender.scala:40-54: personal.csv is split on "," and trimmed; the header row (column 0 == "id") and
-// rows without a third column become rating 0 and are filtered out; the rest are ratings of user 944.  Column 1 is
-// the movie name (for every row, rated or not).  A non-numeric id or rating throws in the reference: fail loudly.
+// recommend/Recommender.scala:40-54 through the library's loader (knncf_load_personal): the non-zero ratings of user 944
+// and every row's (id, title)
 bool load_personal(const std::string& path, Ratings* out, std::vector<std::pair<int32_t, std::string>>* names, std::string* err) {
-    std::ifstream f(path);
-    if (!f) { *err = "cannot open " + path; return false; }
-    std::string line;
-    int64_t lineno = 0;
-    while (std::getline(f, line)) {
-        ++lineno;
-        if (!line.empty() && line.back() == '\r') line.pop_back();
-        std::vector<std::string> cols;
-        size_t pos = 0;
-        while (true) {
-            size_t q = line.find(',', pos);
-            if (q == std::string::npos) { cols.push_back(trim(line.substr(pos))); break; }
-            cols.push_back(trim(line.substr(pos, q - pos)));
-            pos = q + 1;
-        }
-        while (cols.size() > 1 && cols.back().empty()) cols.pop_back();  // String.split drops trailing empties
-        if (cols[0] == "id") { names->push_back({0, "header"}); continue; }
-        int32_t id;
-        if (!parse_int(cols[0], &id) || cols.size() < 2) { *err = path + ":" + std::to_string(lineno) + ": malformed personal row"; return false; }
-        names->push_back({id, cols[1]});
-        if (cols.size() < 3) continue;  // Rating(944, id, 0.0): filtered
-        char* endp = nullptr;
-        const double r = strtod(cols[2].c_str(), &endp);
-        if (cols[2].empty() || *endp != '\0') { *err = path + ":" + std::to_string(lineno) + ": malformed personal rating"; return false; }
-        if (r != 0) {
-            out->users.push_back(944);
-            out->items.push_back(id);
-            out->ratings.push_back(r);
-        }
+    knncf_personal p;
+    char msg[512] = {0};
+    if (knncf_load_personal(path.c_str(), 944, &p, msg, (int)sizeof msg) != KNNCF_OK) { *err = msg; return false; }
+    for (int64_t j = 0; j < p.n_rows; ++j) names->push_back({p.row_ids[j], p.row_names[j]});
+    for (int64_t j = 0; j < p.ratings.n; ++j) {
+        out->users.push_back(p.ratings.users[j]);
+        out->items.push_back(p.ratings.items[j]);
+        out->ratings.push_back(p.ratings.ratings[j]);
     }
+    knncf_free_personal(&p);
     return true;
 }
 

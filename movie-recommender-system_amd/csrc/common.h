@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <stdexcept>
 #include <string>
 
@@ -142,6 +143,33 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
     return x;
 }
 #endif
+
+// Per-device launch state of a kernel, shared by every handle of the process.  hipFuncSetAttribute(MaxDynamicSharedMemorySize)
+// and the occupancy query apply to the device that is current when they run, and handles may live on several devices and be
+// driven from several threads (one JVM, several GPUs: INTEGRATION.md) — so the "already done" memo is kept per device ordinal
+// under a mutex, never in a bare function-level static.
+struct PerDeviceState {
+    static constexpr int MAX_DEVICES = 64;
+    std::mutex mu;
+    size_t value[MAX_DEVICES] = {};
+};
+// runs setup(current value) -> new value when the current device's value is below `want`; returns the device's value
+template <class F>
+inline size_t per_device_at_least(PerDeviceState& state, size_t want, F&& setup) {
+    int dev = 0;
+    KN_HIP(hipGetDevice(&dev));
+    KN_REQUIRE(dev >= 0 && dev < PerDeviceState::MAX_DEVICES, KNNCF_E_UNSUPPORTED, "device ordinal beyond the per-device tables");
+    std::lock_guard<std::mutex> lock(state.mu);
+    if (state.value[dev] < want) state.value[dev] = setup(state.value[dev]);
+    return state.value[dev];
+}
+// enables `bytes` of dynamic LDS for `kernel` on the current device (once per device and size)
+inline void ensure_dynamic_lds(PerDeviceState& state, const void* kernel, size_t bytes) {
+    per_device_at_least(state, bytes, [&](size_t) {
+        KN_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        return bytes;
+    });
+}
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }

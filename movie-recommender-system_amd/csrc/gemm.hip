@@ -16,6 +16,8 @@
 // Tile t+1 stays in flight across the barrier behind a counted vmcnt.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "engine.h"
 
 namespace knncf {
@@ -308,8 +310,9 @@ static void launch_gemm_cfg(const bf16_t* A, const bf16_t* B, OT* C, int64_t M, 
     static_assert(SMEM <= 160 * 1024, "gemm: LDS plan exceeds the CU's 160 KiB");
     const int64_t tiles = (M / TB) * (N / TB);
     KN_REQUIRE(tiles > 0 && tiles < (1ll << 31), KNNCF_E_INVALID, "gemm: grid too large");
-    static int slots = 0;  // resident workgroups on the device
-    if (!slots) {
+    // resident workgroups of this kernel on the CURRENT device (dynamic-LDS attribute, CU count, occupancy): per device
+    static PerDeviceState state;
+    const int64_t slots = (int64_t)per_device_at_least(state, 1, [&](size_t) {
         KN_HIP(hipFuncSetAttribute((const void*)k_gemm_nt_bf16<F16, OT, WM, WN, WAVES_M, WAVES_N>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         int dev = 0, cus = 0, per_cu = 0;
@@ -317,8 +320,8 @@ static void launch_gemm_cfg(const bf16_t* A, const bf16_t* B, OT* C, int64_t M, 
         KN_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         KN_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gemm_nt_bf16<F16, OT, WM, WN, WAVES_M, WAVES_N>,
                                                             WAVES_M * WAVES_N * 64, SMEM));
-        slots = cus * (per_cu > 0 ? per_cu : 1);
-    }
+        return (size_t)std::max(1, cus * (per_cu > 0 ? per_cu : 1));
+    });
     const unsigned grid = (unsigned)(tiles < slots ? tiles : slots);
     k_gemm_nt_bf16<F16, OT, WM, WN, WAVES_M, WAVES_N><<<grid, WAVES_M * WAVES_N * 64, SMEM, st>>>(
         A, B, C, (int)(M / TB), (int)(N / TB), (int)(K / BK), lda, ldb, ldc);

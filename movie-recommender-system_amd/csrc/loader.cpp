@@ -198,6 +198,121 @@ int knncf_load_file(const char* path, const char* separator, int threads, knncf_
     return KNNCF_OK;
 }
 
+// recommend/Recommender.scala:40-54: the Recommender's personal-ratings file.  Per line: split on "," (Java's
+// String.split: trailing EMPTY strings are dropped — before the trim), trim every column; column 0 == "id" is the header
+// row -> (0, "header") in the name list and Rating(user, 0, 0.0); fewer than 3 columns -> rating 0.0; otherwise
+// cols(2).toDouble.  Ratings equal to 0 are filtered out (:50).  cols(0).toInt / cols(2).toDouble throw in the reference:
+// KNNCF_E_INVALID with the line number here.  Every row's (id, cols(1)) goes into the name list (:51-54).
+int knncf_load_personal(const char* path, int32_t user, knncf_personal* out, char* err, int err_cap) {
+    if (!path || !out) { set_err(err, err_cap, "null argument"); return KNNCF_E_INVALID; }
+    memset(out, 0, sizeof *out);
+    FILE* f = fopen(path, "rb");
+    if (!f) { set_err(err, err_cap, std::string("cannot open ") + path + ": " + strerror(errno)); return KNNCF_E_INVALID; }
+    std::string data;
+    {
+        char buf[1 << 16];
+        size_t got;
+        while ((got = fread(buf, 1, sizeof buf, f)) > 0) data.append(buf, got);
+        fclose(f);
+    }
+    std::vector<int32_t> ids, r_items;
+    std::vector<std::string> names;
+    std::vector<double> r_values;
+    auto trimmed = [](const std::string& x) {
+        size_t b = 0, e = x.size();
+        while (b < e && is_space((unsigned char)x[b])) ++b;
+        while (e > b && is_space((unsigned char)x[e - 1])) --e;
+        return x.substr(b, e - b);
+    };
+    int64_t lineno = 0;
+    size_t pos = 0;
+    while (pos < data.size()) {  // textFile: one record per line, no record for the empty tail after the last newline
+        size_t nl = data.find('\n', pos);
+        std::string line = data.substr(pos, nl == std::string::npos ? std::string::npos : nl - pos);
+        pos = nl == std::string::npos ? data.size() : nl + 1;
+        ++lineno;
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        std::vector<std::string> cols;
+        for (size_t p = 0;;) {
+            size_t q = line.find(',', p);
+            cols.push_back(line.substr(p, q == std::string::npos ? std::string::npos : q - p));
+            if (q == std::string::npos) break;
+            p = q + 1;
+        }
+        while (cols.size() > 1 && cols.back().empty()) cols.pop_back();  // String.split(",") drops trailing empty strings
+        if (cols.size() == 1 && cols[0].empty()) cols[0] = "";           // "".split(",") = Array("")
+        for (auto& c : cols) c = trimmed(c);
+        const std::string where = std::string(path) + ":" + std::to_string(lineno) + ": ";
+        if (cols[0] == "id") {
+            ids.push_back(0);
+            names.push_back("header");
+            continue;
+        }
+        int32_t id;
+        if (!parse_int(cols[0].data(), cols[0].data() + cols[0].size(), &id)) {
+            set_err(err, err_cap, where + "column 0 is not an Int");
+            return KNNCF_E_INVALID;
+        }
+        if (cols.size() < 2) {  // cols(1) on a one-column row: ArrayIndexOutOfBoundsException
+            set_err(err, err_cap, where + "no title column");
+            return KNNCF_E_INVALID;
+        }
+        ids.push_back(id);
+        names.push_back(cols[1]);
+        if (cols.size() < 3) continue;  // Rating(user, id, 0.0): filtered
+        double r;
+        if (!parse_double(cols[2].data(), cols[2].data() + cols[2].size(), &r)) {
+            set_err(err, err_cap, where + "column 2 is not a Double");
+            return KNNCF_E_INVALID;
+        }
+        if (r != 0) {
+            r_items.push_back(id);
+            r_values.push_back(r);
+        }
+    }
+    const size_t nr = ids.size(), nq = r_items.size();
+    size_t name_bytes = 0;
+    for (const auto& nm : names) name_bytes += nm.size() + 1;
+    out->row_ids = (int32_t*)malloc((nr ? nr : 1) * sizeof(int32_t));
+    out->row_names = (char**)malloc((nr ? nr : 1) * sizeof(char*));
+    out->name_storage = (char*)malloc(name_bytes ? name_bytes : 1);
+    out->ratings.users = (int32_t*)malloc((nq ? nq : 1) * sizeof(int32_t));
+    out->ratings.items = (int32_t*)malloc((nq ? nq : 1) * sizeof(int32_t));
+    out->ratings.ratings = (double*)malloc((nq ? nq : 1) * sizeof(double));
+    if (!out->row_ids || !out->row_names || !out->name_storage || !out->ratings.users || !out->ratings.items || !out->ratings.ratings) {
+        knncf_free_personal(out);
+        set_err(err, err_cap, "out of host memory");
+        return KNNCF_E_NOMEM;
+    }
+    char* w = out->name_storage;
+    for (size_t j = 0; j < nr; ++j) {
+        out->row_ids[j] = ids[j];
+        out->row_names[j] = w;
+        memcpy(w, names[j].c_str(), names[j].size() + 1);
+        w += names[j].size() + 1;
+    }
+    for (size_t j = 0; j < nq; ++j) {
+        out->ratings.users[j] = user;
+        out->ratings.items[j] = r_items[j];
+        out->ratings.ratings[j] = r_values[j];
+    }
+    out->n_rows = (int64_t)nr;
+    out->ratings.n = (int64_t)nq;
+    return KNNCF_OK;
+}
+
+void knncf_free_personal(knncf_personal* p) {
+    if (!p) return;
+    free(p->row_ids);
+    free(p->row_names);
+    free(p->name_storage);
+    knncf_free_ratings(&p->ratings);
+    p->row_ids = nullptr;
+    p->row_names = nullptr;
+    p->name_storage = nullptr;
+    p->n_rows = 0;
+}
+
 void knncf_free_ratings(knncf_ratings* r) {
     if (!r) return;
     free(r->users);

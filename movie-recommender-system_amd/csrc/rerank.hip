@@ -490,11 +490,8 @@ static void launch_rerank_tile(const Rows& R, const Train& tr, NeighborTable& nt
     const size_t smem = (size_t)TILE * 8 + (size_t)UPRE_LDS * 8 + (size_t)(TPB / 64) * WBUF * 8 + (size_t)TILE * 4 +
                         (size_t)words * 8 + (size_t)(TPB / 64) * WMETA * 4;
     KN_REQUIRE(smem <= 160 * 1024 - 2048, KNNCF_E_UNSUPPORTED, "re-rank: item bitmap does not fit in LDS (too many items)");
-    static size_t attr = 0;
-    if (smem > attr) {
-        KN_HIP(hipFuncSetAttribute((const void*)k_rerank<TILE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr = smem;
-    }
+    static PerDeviceState lds_state;
+    ensure_dynamic_lds(lds_state, (const void*)k_rerank<TILE>, smem);
     k_rerank<TILE><<<n_rows, TPB, smem, st>>>(R, nt.seq.p, n_rows, d_row_user, cap, cand_idx, cand_approx, cand_cnt, nt.kcap,
                                               nt.kcap, nt.idx.p, nt.sim.p, nt.cnt.p, cand_eps, d_stats, d_row_entries, words);
     k_sum_row_entries<<<(unsigned)ceil_div(n_rows, 1024), 1024, 0, st>>>(n_rows, d_row_entries, reinterpret_cast<unsigned long long*>(d_stats) + 1);

@@ -667,11 +667,8 @@ static void launch_tail_select_t(const TailArgs& T, const ST* S, int64_t lds, in
                                  int32_t U, int32_t kk, float eps_opnd, float eps_rest, int32_t cap, int32_t* cand_idx, float* cand_approx,
                                  int32_t* cand_cnt, float* cand_eps, int32_t* grp_v0, float* grp_x, hipStream_t st) {
     const size_t smem = (size_t)TCOLS * 4 + (size_t)NBINS * 4 + (size_t)EMAX * 4 + 2 * ((size_t)EMAX * 12 + (size_t)PMAX * 2) + (2 * (TPB / 64) + 4 + 64) * 4;  // + 64 scratch cells
-    static bool attr_set = false;
-    if (!attr_set) {
-        KN_HIP(hipFuncSetAttribute((const void*)k_tail_select<ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
-    }
+    static PerDeviceState lds_state;
+    ensure_dynamic_lds(lds_state, (const void*)k_tail_select<ST>, smem);
     k_tail_select<ST><<<n_rows, TPB, smem, st>>>(S, lds, n_rows, d_row_user, T, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x);
     KN_HIP(hipGetLastError());
 #ifdef KNNCF_SELECT_PROFILE

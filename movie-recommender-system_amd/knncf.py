@@ -57,6 +57,32 @@ def load_file(path, separator="\t", threads=0):
     return u, i, x
 
 
+class Personal(C.Structure):
+    """knncf_personal of include/knncf.h"""
+    _fields_ = [("n_rows", C.c_int64), ("row_ids", C.POINTER(C.c_int32)), ("row_names", C.POINTER(C.c_char_p)),
+                ("name_storage", C.c_void_p), ("ratings", Ratings)]
+
+
+def load_personal(path, user=944):
+    """recommend/Recommender.scala:40-54 through knncf_load_personal: (names, (users, items, ratings)) — `names` is the
+    list of (id, title) of every row in file order, the header as (0, "header"); the ratings are the non-zero ones."""
+    L = load_library()
+    p = Personal()
+    err = C.create_string_buffer(512)
+    st = L.knncf_load_personal(os.fsencode(path), user, C.byref(p), err, len(err))
+    if st != 0:
+        raise KnncfError(st, err.value.decode(errors="replace"))
+    try:
+        names = [(int(p.row_ids[j]), p.row_names[j].decode("utf-8", errors="replace")) for j in range(p.n_rows)]
+        n = p.ratings.n
+        u = np.ctypeslib.as_array(p.ratings.users, shape=(max(n, 1),))[:n].copy()
+        i = np.ctypeslib.as_array(p.ratings.items, shape=(max(n, 1),))[:n].copy()
+        x = np.ctypeslib.as_array(p.ratings.ratings, shape=(max(n, 1),))[:n].copy()
+    finally:
+        L.knncf_free_personal(C.byref(p))
+    return names, (u, i, x)
+
+
 class Timings(C.Structure):
     _fields_ = [("prep_ms", C.c_double), ("densify_ms", C.c_double), ("gemm_ms", C.c_double),
                 ("tail_ms", C.c_double), ("select_ms", C.c_double), ("rerank_ms", C.c_double), ("predict_ms", C.c_double),
@@ -81,10 +107,10 @@ EXPORTS = [
     "knncf_version", "knncf_status_string", "knncf_create", "knncf_destroy", "knncf_last_error",
     "knncf_fit", "knncf_fit_device", "knncf_num_users", "knncf_num_items", "knncf_global_avg",
     "knncf_user_avg", "knncf_item_avg", "knncf_item_avg_dev", "knncf_item_avg_dev_rdd", "knncf_similarity",
-    "knncf_knn_similarity", "knncf_neighbors", "knncf_predict", "knncf_recommend", "knncf_predict_batch",
+    "knncf_knn_similarity", "knncf_neighbors", "knncf_neighbors_batch", "knncf_predict", "knncf_recommend", "knncf_predict_batch",
     "knncf_predict_batch_device", "knncf_mae", "knncf_mae_device", "knncf_shard_view_get",
     "knncf_shard_commit", "knncf_get_timings", "knncf_reset_timings", "knncf_reset_neighbors",
-    "knncf_set_k", "knncf_load_file", "knncf_free_ratings", "knncf_neighbors_save", "knncf_neighbors_load",
+    "knncf_set_k", "knncf_load_file", "knncf_free_ratings", "knncf_load_personal", "knncf_free_personal", "knncf_neighbors_save", "knncf_neighbors_load",
 ]
 
 
@@ -145,6 +171,7 @@ def load_library():
     for n in ("knncf_similarity", "knncf_knn_similarity"):
         getattr(L, n).argtypes = [C.c_void_p, C.c_int32, C.c_int32, _f64p]
     L.knncf_neighbors.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _i32p, _f64p, _i32p]
+    L.knncf_neighbors_batch.argtypes = [C.c_void_p, _i32p, C.c_int64, C.c_int32, _i32p, _f64p, _i32p]
     L.knncf_predict.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_int32, _f64p]
     L.knncf_recommend.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_int32, _i32p, _f64p, C.POINTER(C.c_int32)]
     L.knncf_predict_batch.argtypes = [C.c_void_p, C.c_int, _i32p, _i32p, C.c_int64, _f64p]
@@ -161,6 +188,9 @@ def load_library():
     L.knncf_load_file.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(Ratings), C.c_char_p, C.c_int]
     L.knncf_free_ratings.argtypes = [C.POINTER(Ratings)]
     L.knncf_free_ratings.restype = None
+    L.knncf_load_personal.argtypes = [C.c_char_p, C.c_int32, C.POINTER(Personal), C.c_char_p, C.c_int]
+    L.knncf_free_personal.argtypes = [C.POINTER(Personal)]
+    L.knncf_free_personal.restype = None
     L.knncf_neighbors_save.argtypes = [C.c_void_p, C.c_char_p]
     L.knncf_neighbors_load.argtypes = [C.c_void_p, C.c_char_p]
     _lib = L
@@ -183,6 +213,15 @@ def _dev_ptr(t, dtype_name):
     if not t.is_cuda or t.dtype != want or not t.is_contiguous():
         raise ValueError(f"expected a contiguous cuda tensor of dtype {dtype_name}")
     return C.c_void_p(t.data_ptr())
+
+
+def _producer_done(t):
+    """The engine runs on its own non-blocking HIP streams and does not know the stream that produced a caller's
+    tensor: the "_device" entry points require their inputs to be COMPLETE at the call (include/knncf.h).  Work queued
+    on torch's current stream of that device is drained here, so tensors produced asynchronously are never read stale."""
+    import torch
+
+    torch.cuda.current_stream(t.device).synchronize()
 
 
 class Engine:
@@ -228,6 +267,7 @@ class Engine:
     def fit_device(self, users, items, ratings):
         """users/items int32, ratings float64: contiguous torch tensors on this engine's device."""
         n = users.numel()
+        _producer_done(users)
         self._check(self._lib.knncf_fit_device(self._h, _dev_ptr(users, "int32"), _dev_ptr(items, "int32"),
                                                _dev_ptr(ratings, "float64"), n))
         return self
@@ -280,6 +320,18 @@ class Engine:
                                               sims.ctypes.data_as(_f64p), C.byref(c)))
         return ids[:c.value].copy(), sims[:c.value].copy()
 
+    def neighbors_batch(self, users):
+        """getNeighbors for many users at once (knncf_neighbors_batch): (ids [n, k], sims [n, k], counts [n]); cells past
+        a row's count are -1 / nan"""
+        u = _i32(users)
+        cap = max(1, self.k)
+        ids = np.full((len(u), cap), -1, dtype=np.int32)
+        sims = np.full((len(u), cap), np.nan, dtype=np.float64)
+        counts = np.zeros(len(u), dtype=np.int32)
+        self._check(self._lib.knncf_neighbors_batch(self._h, u.ctypes.data_as(_i32p), len(u), cap, ids.ctypes.data_as(_i32p),
+                                                    sims.ctypes.data_as(_f64p), counts.ctypes.data_as(_i32p)))
+        return ids, sims, counts
+
     def predict(self, predictor, u, i):
         return self._scalar(self._lib.knncf_predict, predictor, u, i)
 
@@ -319,6 +371,7 @@ class Engine:
         """Partial (sum |r - p|, count) over the rows this shard owns; tensors on the device."""
         s, c = C.c_double(), C.c_int64()
         p = _dev_ptr(pred_out, "float64") if pred_out is not None else None
+        _producer_done(users)
         self._check(self._lib.knncf_mae_device(self._h, predictor, _dev_ptr(users, "int32"), _dev_ptr(items, "int32"),
                                                _dev_ptr(ratings, "float64"), users.numel(), C.byref(s), C.byref(c), p))
         return s.value, c.value

@@ -907,3 +907,298 @@ int32_t orc_recommend(const orc_model* m, orc_pipeline* p, int simple_kind, int3
     free(rated); free(r);
     return cnt;
 }
+
+/* ------------------------------------------------------------------------ */
+/* bulk evaluation on all cores                                              */
+/* ------------------------------------------------------------------------ */
+/*
+ * The same closures — adjustedCosineSimilarityFunction :407-433 under getNeighbors
+ * :596-617, getSimilarity :626-649, weightedSumDeviation :489-549, predictor
+ * :557-586, MAE :69-73 — evaluated for MANY users at once, one user per thread.
+ * This is legal exactly when no user has <= 4 ratings: then no value depends on
+ * the memo history (N6) and every neighbourhood is a pure function of the model.
+ * orc_knn_table_build refuses (ORC_E_INVALID) otherwise.
+ *
+ * Evaluation order.  The per-pair form (cos_value above) walks both users' item
+ * sets in trie order and adds pre(u,i) * pre(v,i) for the common items, left to
+ * right from 0.0.  The row form used here walks u's items in the SAME trie order
+ * and, for each item, adds pre(u,i) * pre(v,i) to acc[v] for every rater v of i:
+ * for a fixed v the additions into acc[v] are the common items of u and v in
+ * ascending trie key, starting from 0.0 — the same operands in the same order,
+ * hence the same bits (tests/test_oracle_bulk.py pins the two forms to each
+ * other on every user of the ml-100k shape and on random cases).  What changes
+ * is the cost: sum_i |U(i)|^2 multiply-adds for all users instead of U * N.
+ *
+ * stable sortWith(_._2 > _._2).take(k) :610 over (allUsers - u).toSeq in Set
+ * order == the k best by (similarity descending, Set position ascending); they
+ * are found with a quickselect on the value and sorted with the same stable
+ * merge sort the per-user path uses.
+ */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+struct orc_knn_table {
+    const orc_model* m;
+    int32_t k, kk; /* requested k, stored width min(k, U-1) */
+    int32_t n_rows;
+    int32_t* row_user;    /* [n_rows] dense user of row r */
+    int32_t* row_of_user; /* [U] row of a dense user or -1 */
+    int32_t* ids;         /* [n_rows * kk] dense neighbour ids, reference order */
+    double* sims;         /* [n_rows * kk] */
+    int64_t* it_ptr;      /* item-major copy: raters (dense user) and their preprocessed ratings */
+    int32_t* it_user;
+    double* it_pre;
+    double* it_dev;       /* normalized deviation of the same entries (file order inside an item, like i_rows) */
+};
+
+static void swap_d(double* a, double* b) { double t = *a; *a = *b; *b = t; }
+
+/* the kth (0-based) LARGEST value of v[0..n) (v is permuted) */
+static double select_desc(double* v, int64_t n, int64_t kth) {
+    int64_t lo = 0, hi = n - 1;
+    while (lo < hi) {
+        int64_t mid = lo + (hi - lo) / 2;
+        /* median of three -> v[mid] */
+        if (v[mid] > v[lo]) swap_d(&v[mid], &v[lo]);
+        if (v[hi] > v[lo]) swap_d(&v[hi], &v[lo]);
+        if (v[hi] > v[mid]) swap_d(&v[hi], &v[mid]);
+        double pv = v[mid];
+        int64_t i = lo, j = hi;
+        while (i <= j) {
+            while (v[i] > pv) ++i;
+            while (v[j] < pv) --j;
+            if (i <= j) { swap_d(&v[i], &v[j]); ++i; --j; }
+        }
+        if (kth <= j) hi = j;
+        else if (kth >= i) lo = i;
+        else return v[kth];
+    }
+    return v[kth];
+}
+
+void orc_knn_table_free(orc_knn_table* t) {
+    if (!t) return;
+    free(t->row_user); free(t->row_of_user); free(t->ids); free(t->sims);
+    free(t->it_ptr); free(t->it_user); free(t->it_pre); free(t->it_dev);
+    free(t);
+}
+
+orc_knn_table* orc_knn_table_build(const orc_model* m, int32_t k, const int32_t* users_raw, int32_t n_users,
+                                   int threads, int* status) {
+    if (status) *status = ORC_OK;
+    if (!m || k < 0 || (users_raw && n_users < 0)) { if (status) *status = ORC_E_INVALID; return NULL; }
+    const int32_t U = m->U;
+    for (int32_t u = 0; u < U; ++u)
+        if (small_row(m, u)) { if (status) *status = ORC_E_INVALID; return NULL; } /* memo-history dependent: use orc_pipeline */
+    orc_knn_table* t = (orc_knn_table*)calloc(1, sizeof(orc_knn_table));
+    t->m = m;
+    t->k = k;
+    t->kk = k < U - 1 ? k : U - 1;
+    if (t->kk < 0) t->kk = 0;
+    t->n_rows = users_raw ? n_users : U;
+    const size_t rows1 = (size_t)(t->n_rows > 0 ? t->n_rows : 1), kk1 = (size_t)(t->kk > 0 ? t->kk : 1);
+    t->row_user = (int32_t*)malloc(sizeof(int32_t) * rows1);
+    t->row_of_user = (int32_t*)malloc(sizeof(int32_t) * (size_t)(U > 0 ? U : 1));
+    for (int32_t u = 0; u < U; ++u) t->row_of_user[u] = -1;
+    for (int32_t r = 0; r < t->n_rows; ++r) {
+        int32_t d = users_raw ? lookup(m->uid, U, users_raw[r]) : r;
+        if (d < 0 || t->row_of_user[d] >= 0) { /* unknown or repeated user */
+            if (status) *status = ORC_E_INVALID;
+            orc_knn_table_free(t);
+            return NULL;
+        }
+        t->row_user[r] = d;
+        t->row_of_user[d] = r;
+    }
+    t->ids = (int32_t*)malloc(sizeof(int32_t) * rows1 * kk1);
+    t->sims = (double*)malloc(sizeof(double) * rows1 * kk1);
+    /* item-major copy (any rater order: each acc[v] receives at most one addend per item) */
+    const size_t nn = (size_t)(m->n > 0 ? m->n : 1);
+    t->it_ptr = (int64_t*)malloc(sizeof(int64_t) * ((size_t)m->I + 1));
+    t->it_user = (int32_t*)malloc(sizeof(int32_t) * nn);
+    t->it_pre = (double*)malloc(sizeof(double) * nn);
+    t->it_dev = (double*)malloc(sizeof(double) * nn);
+    memcpy(t->it_ptr, m->i_ptr, sizeof(int64_t) * ((size_t)m->I + 1));
+    for (int64_t q = 0; q < m->n; ++q) {
+        t->it_user[q] = m->du[m->i_rows[q]];
+        t->it_pre[q] = m->pre[m->i_rows[q]];
+        t->it_dev[q] = m->dev[m->i_rows[q]];
+    }
+    if (t->kk == 0 || t->n_rows == 0) return t;
+    int nomem = 0;
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+#pragma omp parallel num_threads(threads)
+#endif
+    {
+        double* acc = (double*)calloc((size_t)U, sizeof(double));
+        double* val = (double*)malloc(sizeof(double) * (size_t)U);
+        int32_t* pick = (int32_t*)malloc(sizeof(int32_t) * ((size_t)t->kk + 1));
+        int32_t* tmp = (int32_t*)malloc(sizeof(int32_t) * ((size_t)t->kk + 1));
+        if (!acc || !val || !pick || !tmp) {
+#ifdef _OPENMP
+#pragma omp atomic write
+#endif
+            nomem = 1;
+        } else {
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 16)
+#endif
+            for (int32_t r = 0; r < t->n_rows; ++r) {
+                const int32_t du = t->row_user[r];
+                /* :418-426 for every v at once: u's items in trie order (the owner's iteration order) */
+                for (int64_t p = m->u_ptr[du]; p < m->u_ptr[du + 1]; ++p) {
+                    const int64_t tu = m->u_sorted[p];
+                    const double xu = m->pre[tu];
+                    const int32_t it = m->di[tu];
+                    for (int64_t q = t->it_ptr[it]; q < t->it_ptr[it + 1]; ++q) {
+                        const int32_t v = t->it_user[q];
+                        acc[v] = acc[v] + xu * t->it_pre[q];
+                    }
+                }
+                /* :608-610: (allUsers - u).toSeq in Set order, stable sort by similarity descending, take(k):
+                 * everything above the kk-th largest value, then the ties at that value in Set order */
+                int64_t c = 0;
+                for (int32_t x = 0; x < U; ++x)
+                    if (x != du) val[c++] = acc[x];
+                const double thr = select_desc(val, c, t->kk - 1);
+                int32_t n_pick = 0;
+                int64_t n_eq = 0; /* ties at thr, collected in val's storage as dense ids */
+                int32_t* eq = (int32_t*)val;
+                for (int32_t x = 0; x < U; ++x) {
+                    if (x == du) continue;
+                    if (acc[x] > thr) pick[n_pick++] = x;
+                    else if (acc[x] == thr) eq[n_eq++] = x;
+                }
+                const int32_t need_eq = t->kk - n_pick;
+                if (n_eq > need_eq) { /* the need_eq ties that come first in Set order (N3) */
+                    keyed* ks = (keyed*)malloc(sizeof(keyed) * (size_t)n_eq);
+                    for (int64_t j = 0; j < n_eq; ++j) { ks[j].key = (uint32_t)m->user_pos[eq[j]]; ks[j].idx = eq[j]; }
+                    qsort(ks, (size_t)n_eq, sizeof(keyed), cmp_keyed);
+                    for (int32_t j = 0; j < need_eq; ++j) pick[n_pick++] = (int32_t)ks[j].idx;
+                    free(ks);
+                } else {
+                    for (int64_t j = 0; j < n_eq; ++j) pick[n_pick++] = eq[j];
+                }
+                /* into Set order, then the stable sort by value: (similarity descending, Set position ascending) */
+                {
+                    keyed* ks = (keyed*)malloc(sizeof(keyed) * (size_t)(n_pick > 0 ? n_pick : 1));
+                    for (int32_t j = 0; j < n_pick; ++j) { ks[j].key = (uint32_t)m->user_pos[pick[j]]; ks[j].idx = pick[j]; }
+                    qsort(ks, (size_t)n_pick, sizeof(keyed), cmp_keyed);
+                    for (int32_t j = 0; j < n_pick; ++j) pick[j] = (int32_t)ks[j].idx;
+                    free(ks);
+                }
+                stable_sort_desc(pick, n_pick, acc, tmp);
+                for (int32_t j = 0; j < t->kk; ++j) {
+                    t->ids[(size_t)r * t->kk + j] = pick[j];
+                    t->sims[(size_t)r * t->kk + j] = acc[pick[j]];
+                }
+                memset(acc, 0, sizeof(double) * (size_t)U);
+            }
+        }
+        free(acc); free(val); free(pick); free(tmp);
+    }
+    if (nomem) {
+        if (status) *status = ORC_E_NOMEM;
+        orc_knn_table_free(t);
+        return NULL;
+    }
+    return t;
+}
+
+int32_t orc_knn_table_width(const orc_knn_table* t) { return t->kk; }
+int32_t orc_knn_table_rows(const orc_knn_table* t) { return t->n_rows; }
+const double* orc_knn_table_sims(const orc_knn_table* t) { return t->sims; }
+/* raw ids of every stored neighbour, [rows * width]; raw user of every row */
+void orc_knn_table_export_ids(const orc_knn_table* t, int32_t* out_ids, int32_t* out_row_user) {
+    const size_t cells = (size_t)t->n_rows * (size_t)t->kk;
+    for (size_t c = 0; c < cells; ++c) out_ids[c] = t->m->uid[t->ids[c]];
+    for (int32_t r = 0; r < t->n_rows; ++r) out_row_user[r] = t->m->uid[t->row_user[r]];
+}
+
+/* predictor(train, weightedSumDeviation(train, getSimilarity(train, k, cos))) :557-586 over (users, items) with
+ * the table's neighbourhoods; every KNOWN test user must have a row.  out_pred[t] per row (file order); returns
+ * the MAE :69-73 as a left fold in file order when ratings != NULL (else 0).  One user per thread; the per-row
+ * arithmetic is wsd_dense / orc_pipeline_predict above, unchanged: every rater of the item in file order, the
+ * neighbour's similarity or 0.0. */
+double orc_knn_table_predict(const orc_knn_table* t, const int32_t* users, const int32_t* items,
+                             const double* ratings, int64_t n, int threads, double* out_pred, int* status) {
+    const orc_model* m = t->m;
+    const int32_t U = m->U;
+    if (status) *status = ORC_OK;
+    /* rows grouped by dense user (counting sort, file order inside a user) */
+    int32_t* du = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    int64_t* ptr = (int64_t*)calloc((size_t)U + 2, sizeof(int64_t));
+    int64_t* rows = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1));
+    for (int64_t r = 0; r < n; ++r) {
+        du[r] = lookup(m->uid, U, users[r]);
+        if (du[r] >= 0 && t->row_of_user[du[r]] < 0 && t->kk > 0) {
+            if (status) *status = ORC_E_INVALID;
+            free(du); free(ptr); free(rows);
+            return 0.0;
+        }
+        ptr[(du[r] >= 0 ? du[r] : U) + 1]++;
+    }
+    for (int32_t g = 0; g <= U; ++g) ptr[g + 1] += ptr[g];
+    {
+        int64_t* fill = (int64_t*)malloc(sizeof(int64_t) * ((size_t)U + 2));
+        memcpy(fill, ptr, sizeof(int64_t) * ((size_t)U + 2));
+        for (int64_t r = 0; r < n; ++r) rows[fill[du[r] >= 0 ? du[r] : U]++] = r;
+        free(fill);
+    }
+    for (int64_t j = ptr[U]; j < ptr[U + 1]; ++j) out_pred[rows[j]] = m->global_avg; /* usersAvg.getOrElse(u, -1) < 0 :571-574 */
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+#pragma omp parallel num_threads(threads)
+#endif
+    {
+        uint8_t* has = (uint8_t*)calloc((size_t)(U > 0 ? U : 1), 1);
+        double* msim = (double*)calloc((size_t)(U > 0 ? U : 1), sizeof(double));
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 32)
+#endif
+        for (int32_t u = 0; u < U; ++u) {
+            if (ptr[u] == ptr[u + 1]) continue;
+            const int32_t row = t->kk > 0 ? t->row_of_user[u] : -1;
+            for (int32_t j = 0; row >= 0 && j < t->kk; ++j) {
+                has[t->ids[(size_t)row * t->kk + j]] = 1;
+                msim[t->ids[(size_t)row * t->kk + j]] = t->sims[(size_t)row * t->kk + j];
+            }
+            for (int64_t j = ptr[u]; j < ptr[u + 1]; ++j) {
+                const int64_t r = rows[j];
+                const int32_t it = lookup(m->iid, m->I, items[r]);
+                double w = 0.0;
+                if (it >= 0) { /* :513-547 */
+                    double num = 0.0, den = 0.0;
+                    /* ratedI(i) in file order: (rater, deviation) = (m->du[t], m->dev[t]) for t in i_rows, read from
+                     * the table's contiguous copies */
+                    for (int64_t q = m->i_ptr[it]; q < m->i_ptr[it + 1]; ++q) {
+                        const int32_t x = t->it_user[q];
+                        const double s = has[x] ? 0.0 + msim[x] : 0.0; /* getSimilarity :638-641 */
+                        num = num + t->it_dev[q] * s;
+                        den = den + fabs(s);
+                    }
+                    w = den > 0 ? num / den : 0.0;
+                }
+                const double ua = m->user_avg[u];
+                out_pred[r] = ua < 0.0 ? m->global_avg : ua + w * orc_scale(ua + w, ua);
+            }
+            for (int32_t j = 0; row >= 0 && j < t->kk; ++j) has[t->ids[(size_t)row * t->kk + j]] = 0;
+        }
+        free(has); free(msim);
+    }
+    double s = 0.0;
+    if (ratings)
+        for (int64_t r = 0; r < n; ++r) s = fabs(ratings[r] - out_pred[r]) + s;
+    free(du); free(ptr); free(rows);
+    return ratings ? s / (double)n : 0.0;
+}
+
+int orc_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -125,6 +125,27 @@ double orc_pipeline_mae(orc_pipeline*, const int32_t* users, const int32_t* item
 int32_t orc_recommend(const orc_model*, orc_pipeline* p, int simple_kind, int32_t user, int32_t n,
                       int32_t* out_items, double* out_preds);
 
+/* ---- bulk evaluation on all cores (OpenMP) --------------------------------
+ * The kNN closures (cosine similarity, k >= 0) evaluated for many users at once,
+ * one user per thread; refused (ORC_E_INVALID) when some user has <= 4 ratings,
+ * because then values depend on the memo history (use orc_pipeline).  Same
+ * operands in the same order as the per-pair closures — see the comment in
+ * knncf_oracle.c; tests/test_oracle_bulk.py pins the two forms to each other. */
+typedef struct orc_knn_table orc_knn_table;
+/* users_raw == NULL: every user, row r = r-th smallest raw id.  threads <= 0: all cores */
+orc_knn_table* orc_knn_table_build(const orc_model*, int32_t k, const int32_t* users_raw, int32_t n_users,
+                                   int threads, int* status);
+void orc_knn_table_free(orc_knn_table*);
+int32_t orc_knn_table_width(const orc_knn_table*); /* min(k, U-1) */
+int32_t orc_knn_table_rows(const orc_knn_table*);
+const double* orc_knn_table_sims(const orc_knn_table*); /* [rows * width], reference order */
+void orc_knn_table_export_ids(const orc_knn_table*, int32_t* out_ids /*[rows*width] raw*/, int32_t* out_row_user /*[rows] raw*/);
+/* predictions of predictor(train, weightedSumDeviation(train, getSimilarity(train,k,cos))) for every row; returns
+ * the MAE (left fold, file order) when ratings != NULL */
+double orc_knn_table_predict(const orc_knn_table*, const int32_t* users, const int32_t* items, const double* ratings,
+                             int64_t n, int threads, double* out_pred, int* status);
+int orc_max_threads(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,6 +96,21 @@ def lib():
     L.orc_pipeline_mae.argtypes = [C.c_void_p, _i32p, _i32p, _f64p, C.c_int64, _f64p]
     L.orc_recommend.restype = C.c_int32
     L.orc_recommend.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int32, C.c_int32, _i32p, _f64p]
+    L.orc_knn_table_build.restype = C.c_void_p
+    L.orc_knn_table_build.argtypes = [C.c_void_p, C.c_int32, _i32p, C.c_int32, C.c_int, C.POINTER(C.c_int)]
+    L.orc_knn_table_free.restype = None
+    L.orc_knn_table_free.argtypes = [C.c_void_p]
+    L.orc_knn_table_width.restype = C.c_int32
+    L.orc_knn_table_width.argtypes = [C.c_void_p]
+    L.orc_knn_table_rows.restype = C.c_int32
+    L.orc_knn_table_rows.argtypes = [C.c_void_p]
+    L.orc_knn_table_sims.restype = _f64p
+    L.orc_knn_table_sims.argtypes = [C.c_void_p]
+    L.orc_knn_table_export_ids.restype = None
+    L.orc_knn_table_export_ids.argtypes = [C.c_void_p, _i32p, _i32p]
+    L.orc_knn_table_predict.restype = C.c_double
+    L.orc_knn_table_predict.argtypes = [C.c_void_p, _i32p, _i32p, _f64p, C.c_int64, C.c_int, _f64p, C.POINTER(C.c_int)]
+    L.orc_max_threads.restype = C.c_int
     _lib = L
     return L
 
@@ -228,6 +243,61 @@ class Model:
 
     def pipeline(self, sim_kind=SIM_COSINE, k=-1):
         return Pipeline(self, sim_kind, k)
+
+    def knn_table(self, k, users=None, threads=0):
+        """The kNN closures (cosine, k) for many users at once on all cores (every user when users is None)."""
+        return KnnTable(self, k, users, threads)
+
+
+def host_threads(cap=64):
+    """Threads the bulk evaluation may use: the CPUs this process is allowed on (the GPU box hands out a share)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, cap))
+
+
+class KnnTable:
+    """orc_knn_table: getNeighbors(train, k, adjustedCosine) of many users + the predictor over them, threaded.
+    Refused (OracleError) when a user has <= 4 ratings: use Pipeline, which models the memo history."""
+
+    def __init__(self, model, k, users=None, threads=0):
+        self.model = model
+        self.threads = threads if threads > 0 else host_threads()
+        st = C.c_int(0)
+        if users is None:
+            self._h = lib().orc_knn_table_build(model._h, k, None, 0, self.threads, C.byref(st))
+        else:
+            u = _i32(users)
+            self._h = lib().orc_knn_table_build(model._h, k, _p(u, _i32p), len(u), self.threads, C.byref(st))
+        if not self._h:
+            raise OracleError(st.value)
+        self.rows = lib().orc_knn_table_rows(self._h)
+        self.width = lib().orc_knn_table_width(self._h)
+        cells = self.rows * self.width
+        self.ids = np.empty((self.rows, self.width), dtype=np.int32)   # raw neighbour ids, reference order
+        self.row_user = np.empty(self.rows, dtype=np.int32)             # raw user of each row
+        lib().orc_knn_table_export_ids(self._h, _p(self.ids, _i32p), _p(self.row_user, _i32p))
+        self.sims = (np.ctypeslib.as_array(lib().orc_knn_table_sims(self._h), shape=(max(cells, 1),))[:cells]
+                     .reshape(self.rows, self.width))                    # view of the table's memory
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self.sims = None
+            lib().orc_knn_table_free(self._h)
+            self._h = None
+
+    def mae(self, users, items, ratings):
+        """(MAE as the reference's left fold, per-row predictions)"""
+        u, i, r = _i32(users), _i32(items), _f64(ratings)
+        per = np.empty(len(u), dtype=np.float64)
+        st = C.c_int(0)
+        m = lib().orc_knn_table_predict(self._h, _p(u, _i32p), _p(i, _i32p), _p(r, _f64p), len(u), self.threads,
+                                        _p(per, _f64p), C.byref(st))
+        if st.value != 0:
+            raise OracleError(st.value)
+        return m, per
 
 
 class Pipeline:

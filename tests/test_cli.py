@@ -110,7 +110,7 @@ def test_recommender_size_assert_and_personal_quirks(cli, tmp_path):
     bad = tmp_path / "bad.csv"
     bad.write_text("id,title,rating\nabc,Movie,5\n")  # cols(0).toInt throws in the reference
     out = subprocess.run([cli, "recommend", "--data", str(data), "--personal", str(bad), "--any-size"], capture_output=True, text=True)
-    assert out.returncode == 1 and "malformed personal row" in out.stderr
+    assert out.returncode == 1 and "bad.csv:2: column 0 is not an Int" in out.stderr
     out = subprocess.run([cli, "recommend", "--data", str(data)], capture_output=True, text=True)
     assert out.returncode == 2
 

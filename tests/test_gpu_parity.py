@@ -345,55 +345,128 @@ def test_prediction_without_item_bitmaps(kn, oracle, synth, monkeypatch):
     e.close()
 
 
-def test_full_size_ml25m_shape_sampled_rows_and_invariants(kn, oracle, synth):
-    """BASELINE's metric configuration (162 541 x 59 047, 20 M / 5 M ratings, k = 300): the oracle cannot
-    finish all rows in seconds, so (i) a sample of users is checked bit for bit (neighbour ids, fp64
-    similarities, predictions), (ii) size-independent properties are checked on everything."""
+@pytest.fixture(scope="module")
+def full25m(kn, oracle, synth):
+    """BASELINE's metric configuration (syn-25m: 162 541 x 59 047, 20 M / 5 M ratings, k = 300) run ONCE through the
+    single-GPU engine with KNNCF_FLAG_VERIFY_BOUND, and the oracle's bulk form (all cores) of the same closures."""
     import torch
 
     d = synth.syn_25m()
     dev = torch.device("cuda", 0)
     tr = tuple(torch.from_numpy(a).to(dev) for a in (d.train.users, d.train.items, d.train.ratings))
     te = tuple(torch.from_numpy(a).to(dev) for a in (d.test.users, d.test.items, d.test.ratings))
-    e = kn.Engine(k=300)
+    e = kn.Engine(k=300, flags=kn.FLAG_VERIFY_BOUND)
     e.fit_device(*tr)
     preds = torch.zeros(len(d.test.users), dtype=torch.float64, device=dev)
     s, c = e.mae_device(kn.PRED_KNN, *te, pred_out=preds)
-    preds = preds.cpu().numpy()
-    assert c == len(d.test.users)
-    mae = s / c
-    # (half-star data: deviations are normalised for a 1..5 scale, so a 0.5 rating can push a prediction
-    # outside [1, 5] — in the reference too; only finiteness is an invariant here)
-    assert np.all(np.isfinite(preds))
-    assert abs(mae - np.abs(d.test.ratings - preds).mean()) < 1e-9           # checksum of the per-row outputs
-    t = e.timings()
-    assert t["fallback_rows"] == 0 and t["head_items"] > 0
-    # idempotence: a second pass over the same test set (neighbourhoods already built) gives the same sums
-    s2, c2 = e.mae_device(kn.PRED_KNN, *te)
-    assert (s2, c2) == (s, c)
     m = oracle.Model(d.train.users, d.train.items, d.train.ratings)
-    rng = np.random.default_rng(3)
-    heavy = np.argsort(np.bincount(d.train.users))[-3:]                      # the three heaviest raters too
-    sample = np.unique(np.concatenate([rng.choice(np.unique(d.test.users), 21, replace=False), heavy, [1, 2]]))
-    p = m.pipeline(oracle.SIM_COSINE, 300)
-    for u in sample:
-        ids, sims = e.neighbors(int(u))
-        oids, osims = p.neighbors(int(u))
-        assert len(ids) == 300 and int(u) not in ids.tolist()
-        assert ids.tolist() == oids.tolist(), f"user {u}"
-        assert sims.tolist() == osims.tolist()
-        assert all(sims[j] >= sims[j + 1] for j in range(299))
-    mask = np.isin(d.test.users, sample)
-    _, opreds = p.mae(d.test.users[mask], d.test.items[mask], d.test.ratings[mask], True)
-    np.testing.assert_array_equal(preds[mask], opreds)
+    out = {"d": d, "tr": tr, "te": te, "engine": e, "preds": preds.cpu().numpy(), "sum": s, "count": c, "model": m,
+           "timings": e.timings()}
+    yield out
+    e.close()
+
+
+def test_full_size_ml25m_shape_every_row_against_the_oracle(kn, oracle, full25m):
+    """predict/kNN.scala:42-45 at the headline shape, COMPLETE coverage: all 162 541 neighbour lists (ids and fp64
+    similarities, bit for bit), all 5 000 019 predictions (bit for bit) and the MAE (1e-9; north_star 1e-6) against the
+    oracle's bulk form (tests/test_oracle_bulk.py pins that form to the literal per-pair closures).  A true neighbour
+    dropped by the 16-bit filter would show as a differing list, so this also validates the error band of
+    select.hip at the one shape that is benchmarked."""
+    f = full25m
+    d, e, m, preds = f["d"], f["engine"], f["model"], f["preds"]
+    n_test = len(d.test.users)
+    assert f["count"] == n_test and np.all(np.isfinite(preds))
+    t = f["timings"]
+    assert t["fallback_rows"] == 0 and t["head_items"] > 0
+    assert t["max_bound_violation"] <= 0.0          # |approx - exact| <= eps on every re-ranked pair
+    table = m.knn_table(300)                        # every user, all host cores
+    assert table.rows == e.num_users == 162_541 and table.width == 300
+    ids, sims, counts = e.neighbors_batch(table.row_user)
+    assert (counts == 300).all()
+    bad = np.flatnonzero((ids != table.ids).any(axis=1))
+    assert len(bad) == 0, f"{len(bad)} neighbour lists differ, first user {table.row_user[bad[0]]}"
+    assert np.array_equal(sims.view(np.int64), table.sims.view(np.int64))   # fp64 similarities, bitwise
+    del ids, sims
+    want, opreds = table.mae(d.test.users, d.test.items, d.test.ratings)
+    diff = np.flatnonzero(preds.view(np.int64) != opreds.view(np.int64))
+    assert len(diff) == 0, f"{len(diff)} of {n_test} predictions differ, first row {diff[0]}"
+    mae = f["sum"] / f["count"]
+    assert abs(mae - want) <= MAE_TOL, (mae, want)
+    # idempotence: a second pass over the same test set (neighbourhoods already built) gives the same sums
+    s2, c2 = e.mae_device(kn.PRED_KNN, *f["te"])
+    assert (s2, c2) == (f["sum"], f["count"])
+    # the closed forms at this size
     assert e.global_avg() == m.average()
-    for u in sample[:5]:
+    for u in table.row_user[:: 40_000]:
         assert e.user_avg(int(u)) == m.users_avg(int(u))
     for i in np.unique(d.test.items)[:5]:
         assert e.item_avg_dev(int(i)) == m.items_avg_dev(int(i))
     want_b = m.mae(oracle.KIND_BASELINE, d.test.users, d.test.items, d.test.ratings)
-    sb, cb = e.mae_device(kn.PRED_BASELINE, *te)
+    sb, cb = e.mae_device(kn.PRED_BASELINE, *f["te"])
     assert sb / cb == pytest.approx(want_b, abs=MAE_TOL)
+
+
+def test_ml25m_shape_eight_shards_on_one_gpu(kn, pkg, full25m):
+    """BASELINE config 4 (kNN k = 300 on ml-25m shape, users sharded x8) rehearsed on ONE GPU: eight handles with
+    shard_rank 0..7 go through the C-ABI shard protocol (fit -> view -> exchange -> commit -> partial MAE); the exchange
+    that RCCL's all-gather performs between GPUs is done by device copies.  Every prediction must equal the single
+    engine's bit for bit (which the test above pins to the oracle), the partial sums must add up to its MAE, and each
+    shard's stage timings are written out: they are the per-rank step times of the 8-GPU run the driver performs
+    (gpurun_out/shard8_timings.json -> DESIGN.md's projected scaling)."""
+    import json
+    import os
+
+    import torch
+
+    sharded = importlib.import_module(pkg.__name__ + ".sharded")
+    f = full25m
+    d, tr, te = f["d"], f["tr"], f["te"]
+    dev = tr[0].device
+    world = 8
+    engines = [kn.Engine(k=300, shard_rank=r, shard_count=world) for r in range(world)]
+    views = []
+    for e in engines:
+        e.reset_timings()
+        e.fit_device(*tr)
+        views.append(sharded.DeviceEngineAdapter(e, dev).shard_tensors())
+    for r in range(1, world):
+        assert views[r - 1]["user_range"][1] == views[r]["user_range"][0]
+    assert views[0]["user_range"][0] == 0 and views[-1]["user_range"][1] == engines[0].num_users
+    for me in range(world):
+        for other in range(world):
+            if other == me:
+                continue
+            ulo, uhi = views[other]["user_range"]
+            nlo, nhi = views[other]["nnz_range"]
+            for key, lo, hi in (("user_avg", ulo, uhi), ("user_norm", ulo, uhi), ("dev", nlo, nhi), ("pre", nlo, nhi)):
+                views[me][key][lo:hi] = views[other][key][lo:hi]
+    torch.cuda.synchronize()
+    total, count = 0.0, 0
+    preds = torch.full((len(d.test.users),), float("nan"), dtype=torch.float64, device=dev)
+    report = []
+    for r, e in enumerate(engines):
+        e.shard_commit()
+        s, c = e.mae_device(kn.PRED_KNN, *te, pred_out=preds)
+        total += s
+        count += c
+        t = e.timings()
+        assert t["fallback_rows"] == 0
+        stage = {k_: t[k_] for k_ in ("prep_ms", "densify_ms", "gemm_ms", "select_ms", "rerank_ms", "predict_ms")}
+        ulo, uhi = views[r]["user_range"]
+        nlo, nhi = views[r]["nnz_range"]
+        report.append({"rank": r, "users": uhi - ulo, "train_ratings": nhi - nlo, "test_rows": c, "stage_ms": stage,
+                       "step_ms": sum(stage.values())})
+        e.close()
+    assert count == f["count"] == len(d.test.users)
+    got = preds.cpu().numpy()
+    assert np.array_equal(got.view(np.int64), f["preds"].view(np.int64))    # every prediction, bit for bit
+    assert total / count == pytest.approx(f["sum"] / f["count"], abs=1e-12)  # only the order of the final sum differs
+    single = {k_: f["timings"][k_] for k_ in ("prep_ms", "densify_ms", "gemm_ms", "select_ms", "rerank_ms", "predict_ms")}
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "shard8_timings.json"), "w") as fh:
+        json.dump({"workload": "syn-25m k=300, 8 shards rehearsed on one MI355X (one after the other)",
+                   "single_engine_stage_ms_with_verify_flag": single, "single_engine_step_ms": sum(single.values()),
+                   "shards": report, "projected_step_ms_8gpu_excl_exchange": max(x["step_ms"] for x in report)}, fh, indent=1)
 
 
 def test_fit_errors(kn):
