@@ -64,9 +64,11 @@ def cpu_baseline(split, k, budget_s, n_test_total):
 
     O.build()
     tr, te = split.train, split.test
+    O.set_threads(1)  # the fit below is part of the single-threaded baseline
     t0 = time.perf_counter()
     model = O.Model(tr.users, tr.items, tr.ratings)
     t_fit = time.perf_counter() - t0
+    O.set_threads(0)
     # first-appearance order of test users
     _, first = np.unique(te.users, return_index=True)
     order = te.users[np.sort(first)]

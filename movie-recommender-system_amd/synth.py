@@ -59,9 +59,14 @@ def _user_counts(rng, n_users, n_ratings, min_per_user, max_per_user, sigma):
 
 
 def make_ratings(n_users, n_items, n_ratings, *, seed, half_stars, max_item_id=None,
-                 min_per_user=20, activity_sigma=1.0, zipf_s=1.0, zipf_q=25.0):
-    """(user, item, rating) triples sorted by (user, item) — the order of MovieLens' own files."""
+                 min_per_user=20, activity_sigma=1.0, zipf_s=1.0, zipf_q=25.0, item_seed=None, first_user=1):
+    """(user, item, rating) triples sorted by (user, item) — the order of MovieLens' own files.
+
+    item_seed (optional): the item side (popularity permutation, raw ids, biases) comes from its own generator, so that
+    several calls with different `seed` / `first_user` produce disjoint blocks of users over the SAME item catalogue
+    (syn_1m builds its 10^6 users as independent blocks, in parallel)."""
     rng = np.random.Generator(np.random.PCG64(seed))
+    irng = rng if item_seed is None else np.random.Generator(np.random.PCG64(item_seed))
     max_per_user = max(min_per_user, int(n_items * 0.55))
     counts = _user_counts(rng, n_users, n_ratings, min_per_user, max_per_user, activity_sigma)
 
@@ -69,7 +74,7 @@ def make_ratings(n_users, n_items, n_ratings, *, seed, half_stars, max_item_id=N
     w = 1.0 / (np.arange(n_items, dtype=np.float64) + zipf_q) ** zipf_s
     cdf = np.cumsum(w / w.sum())
     cdf[-1] = 1.0
-    slot_of_rank = rng.permutation(n_items).astype(np.int64)
+    slot_of_rank = irng.permutation(n_items).astype(np.int64)
 
     # Draw items WITH replacement and de-duplicate.  d draws give
     # E(d) = sum_i 1 - (1 - p_i)^d distinct items; invert E on a grid so that one round
@@ -120,11 +125,11 @@ def make_ratings(n_users, n_items, n_ratings, *, seed, half_stars, max_item_id=N
     if max_item_id is None:
         raw_items = np.arange(1, n_items + 1, dtype=np.int64)
     else:
-        raw_items = np.sort(rng.choice(max_item_id, size=n_items, replace=False).astype(np.int64) + 1)
+        raw_items = np.sort(irng.choice(max_item_id, size=n_items, replace=False).astype(np.int64) + 1)
     # popularity rank -> bias: popular items rate slightly higher, like MovieLens
     rank_of_slot = np.empty(n_items, dtype=np.int64)
     rank_of_slot[slot_of_rank] = np.arange(n_items)
-    item_bias = rng.normal(0.0, 0.45, n_items) + 0.35 * (1.0 - rank_of_slot / n_items) - 0.15
+    item_bias = irng.normal(0.0, 0.45, n_items) + 0.35 * (1.0 - rank_of_slot / n_items) - 0.15
     user_bias = rng.normal(0.0, 0.45, n_users)
     raw = 3.35 + user_bias[users] + item_bias[slots] + rng.normal(0.0, 0.95, len(users))
     if half_stars:
@@ -137,7 +142,7 @@ def make_ratings(n_users, n_items, n_ratings, *, seed, half_stars, max_item_id=N
             ratings[m] = 1.0
     else:
         ratings = np.clip(np.round(raw), 1.0, 5.0)
-    return RatingSet((users + 1).astype(np.int32), raw_items[slots].astype(np.int32),
+    return RatingSet((users + first_user).astype(np.int32), raw_items[slots].astype(np.int32),
                      ratings.astype(np.float64))
 
 
@@ -179,11 +184,42 @@ def syn_25m(seed=25, shuffle=False):
     return split_80_20(rs, seed=seed, shuffle=shuffle, name="syn-25m")
 
 
-def syn_1m(seed=1000, shuffle=False):
-    """Roofline-stress shape: 1 M users x 100 k items, 250 M integer ratings, 80/20."""
-    rs = make_ratings(1_000_000, 100_000, 250_000_000, seed=seed, half_stars=False, min_per_user=20,
-                      activity_sigma=1.0, zipf_s=1.0, zipf_q=25.0)
-    return split_80_20(rs, seed=seed, shuffle=shuffle, name="syn-1M")
+def syn_blocks(n_users, n_items, n_ratings, *, seed, n_blocks, half_stars, name, workers=0, **kw):
+    """A big set as n_blocks independent blocks of users over one item catalogue (item_seed = seed), generated and split
+    80/20 block by block on a thread pool (numpy releases the GIL in its sorts and gathers) and concatenated in user
+    order.  Deterministic in (arguments, n_blocks); independent of the number of workers."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+
+    if n_users % n_blocks or n_ratings % n_blocks:
+        raise ValueError("n_users and n_ratings must be multiples of n_blocks")
+    bu, bn = n_users // n_blocks, n_ratings // n_blocks
+
+    def one(b):
+        rs = make_ratings(bu, n_items, bn, seed=seed + 7919 * (b + 1), half_stars=half_stars, item_seed=seed,
+                          first_user=1 + b * bu, **kw)
+        sp = split_80_20(rs, seed=seed + 7919 * (b + 1))
+        return sp.train, sp.test
+
+    if workers <= 0:
+        try:
+            workers = len(os.sched_getaffinity(0))
+        except AttributeError:
+            workers = os.cpu_count() or 1
+    workers = max(1, min(workers, n_blocks, 32))
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        parts = list(ex.map(one, range(n_blocks)))
+    cat = lambda j: RatingSet(np.concatenate([getattr(p[j], "users") for p in parts]),
+                              np.concatenate([getattr(p[j], "items") for p in parts]),
+                              np.concatenate([getattr(p[j], "ratings") for p in parts]))
+    return Split(cat(0), cat(1), name)
+
+
+def syn_1m(seed=1000, n_blocks=64, workers=0):
+    """Roofline-stress shape (BASELINE config 5): 1 M users x 100 k items, 250 M integer ratings, 80/20 — built as 64
+    blocks of 15 625 users (3 906 250 ratings each) over one item catalogue."""
+    return syn_blocks(1_000_000, 100_000, 250_000_000, seed=seed, n_blocks=n_blocks, half_stars=False, name="syn-1M",
+                      workers=workers, min_per_user=20, activity_sigma=1.0, zipf_s=1.0, zipf_q=25.0)
 
 
 def syn_scaled(n_users, n_items, n_ratings, seed, half_stars=True, shuffle=False, max_item_id=None):

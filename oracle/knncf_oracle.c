@@ -164,7 +164,33 @@ static int32_t lookup(const int32_t* ids, int32_t n, int32_t raw) {
     return (lo < n && ids[lo] == raw) ? lo : -1;
 }
 
+/* distinct values ascending.  Non-negative ids (every MovieLens id) go through a presence bitmap, O(n + max/64);
+ * anything else through qsort.  Plumbing only: no arithmetic of the reference happens here. */
 static int32_t* distinct_sorted(const int32_t* v, int64_t n, int32_t* count) {
+    int32_t lo = 0, hi = -1;
+    for (int64_t i = 0; i < n; ++i) {
+        if (i == 0 || v[i] < lo) lo = v[i];
+        if (i == 0 || v[i] > hi) hi = v[i];
+    }
+    if (n > 0 && lo >= 0) {
+        const size_t words = ((size_t)hi >> 6) + 1;
+        uint64_t* bits = (uint64_t*)calloc(words, sizeof(uint64_t));
+        for (int64_t i = 0; i < n; ++i) bits[(uint32_t)v[i] >> 6] |= 1ull << ((uint32_t)v[i] & 63u);
+        int64_t c = 0;
+        for (size_t w = 0; w < words; ++w) c += __builtin_popcountll(bits[w]);
+        int32_t* out = (int32_t*)malloc(sizeof(int32_t) * (size_t)(c > 0 ? c : 1));
+        int64_t k = 0;
+        for (size_t w = 0; w < words; ++w) {
+            uint64_t x = bits[w];
+            while (x) {
+                out[k++] = (int32_t)((w << 6) + (size_t)__builtin_ctzll(x));
+                x &= x - 1;
+            }
+        }
+        free(bits);
+        *count = (int32_t)c;
+        return out;
+    }
     int32_t* tmp = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
     memcpy(tmp, v, sizeof(int32_t) * (size_t)n);
     qsort(tmp, (size_t)n, sizeof(int32_t), cmp_i32);
@@ -221,6 +247,7 @@ orc_model* orc_fit(const int32_t* users, const int32_t* items, const double* rat
     m->iid = distinct_sorted(items, n, &m->I);
     m->du = (int32_t*)malloc(sizeof(int32_t) * nn);
     m->di = (int32_t*)malloc(sizeof(int32_t) * nn);
+#pragma omp parallel for schedule(static)
     for (int64_t t = 0; t < n; ++t) {
         m->du[t] = lookup(m->uid, m->U, users[t]);
         m->di[t] = lookup(m->iid, m->I, items[t]);
@@ -233,21 +260,32 @@ orc_model* orc_fit(const int32_t* users, const int32_t* items, const double* rat
 
     /* per-user rows sorted by item trie key; duplicate (user,item) -> error */
     m->u_sorted = (int64_t*)malloc(sizeof(int64_t) * nn);
+    int64_t max_row = 1, max_col = 1;
+    for (int32_t u = 0; u < m->U; ++u)
+        if (m->u_ptr[u + 1] - m->u_ptr[u] > max_row) max_row = m->u_ptr[u + 1] - m->u_ptr[u];
+    for (int32_t i = 0; i < m->I; ++i)
+        if (m->i_ptr[i + 1] - m->i_ptr[i] > max_col) max_col = m->i_ptr[i + 1] - m->i_ptr[i];
     {
-        keyed* ks = (keyed*)malloc(sizeof(keyed) * nn);
-        for (int32_t u = 0; u < m->U && st == ORC_OK; ++u) {
-            int64_t b = m->u_ptr[u], e = m->u_ptr[u + 1];
-            for (int64_t p = b; p < e; ++p) {
-                ks[p - b].key = m->item_key[m->di[m->u_rows[p]]];
-                ks[p - b].idx = m->u_rows[p];
+        int dup = 0;
+#pragma omp parallel reduction(| : dup)
+        {
+            keyed* ks = (keyed*)malloc(sizeof(keyed) * (size_t)max_row);
+#pragma omp for schedule(dynamic, 256)
+            for (int32_t u = 0; u < m->U; ++u) {
+                int64_t b = m->u_ptr[u], e = m->u_ptr[u + 1];
+                for (int64_t p = b; p < e; ++p) {
+                    ks[p - b].key = m->item_key[m->di[m->u_rows[p]]];
+                    ks[p - b].idx = m->u_rows[p];
+                }
+                qsort(ks, (size_t)(e - b), sizeof(keyed), cmp_keyed);
+                for (int64_t p = b; p < e; ++p) {
+                    m->u_sorted[p] = ks[p - b].idx;
+                    if (p > b && ks[p - b].key == ks[p - b - 1].key) dup = 1;
+                }
             }
-            qsort(ks, (size_t)(e - b), sizeof(keyed), cmp_keyed);
-            for (int64_t p = b; p < e; ++p) {
-                m->u_sorted[p] = ks[p - b].idx;
-                if (p > b && ks[p - b].key == ks[p - b - 1].key) st = ORC_E_DUPLICATE;
-            }
+            free(ks);
         }
-        free(ks);
+        if (dup) st = ORC_E_DUPLICATE;
     }
 
     /* N3: iteration order of ratings.map(_.user).toSet (:599) */
@@ -281,12 +319,14 @@ orc_model* orc_fit(const int32_t* users, const int32_t* items, const double* rat
     }
     /* usersAvg :113 / itemsAvg :134 — groupBy + average, file order */
     m->user_avg = (double*)malloc(sizeof(double) * (size_t)(m->U > 0 ? m->U : 1));
+#pragma omp parallel for schedule(dynamic, 1024)
     for (int32_t u = 0; u < m->U; ++u) {
         double s = 0.0;
         for (int64_t p = m->u_ptr[u]; p < m->u_ptr[u + 1]; ++p) s = s + ratings[m->u_rows[p]];
         m->user_avg[u] = s / (double)(m->u_ptr[u + 1] - m->u_ptr[u]);
     }
     m->item_avg = (double*)malloc(sizeof(double) * (size_t)(m->I > 0 ? m->I : 1));
+#pragma omp parallel for schedule(dynamic, 64)
     for (int32_t i = 0; i < m->I; ++i) {
         double s = 0.0;
         for (int64_t p = m->i_ptr[i]; p < m->i_ptr[i + 1]; ++p) s = s + ratings[m->i_rows[p]];
@@ -295,10 +335,15 @@ orc_model* orc_fit(const int32_t* users, const int32_t* items, const double* rat
 
     /* computeNormalizeDeviation :155-169 */
     m->dev = (double*)malloc(sizeof(double) * nn);
-    for (int64_t t = 0; t < n; ++t) {
-        double ua = m->user_avg[m->du[t]];
-        m->dev[t] = (ratings[t] - ua) / orc_scale(ratings[t], ua);
-        if (!isfinite(m->dev[t]) && st == ORC_OK) st = ORC_E_NONFINITE;
+    {
+        int nonfinite = 0;
+#pragma omp parallel for schedule(static) reduction(| : nonfinite)
+        for (int64_t t = 0; t < n; ++t) {
+            double ua = m->user_avg[m->du[t]];
+            m->dev[t] = (ratings[t] - ua) / orc_scale(ratings[t], ua);
+            if (!isfinite(m->dev[t])) nonfinite = 1;
+        }
+        if (nonfinite && st == ORC_OK) st = ORC_E_NONFINITE;
     }
 
     /* preprocessedRating :470-481.  usersWeights :474 folds x.map(pow(_,2)).sum over
@@ -306,8 +351,10 @@ orc_model* orc_fit(const int32_t* users, const int32_t* items, const double* rat
      * hash (N4); hash collisions keep insertion (= file) order.  pow(x,2) == x*x. */
     m->weight = (double*)malloc(sizeof(double) * (size_t)(m->U > 0 ? m->U : 1));
     m->pre = (double*)malloc(sizeof(double) * nn);
+#pragma omp parallel
     {
-        keyed* ks = (keyed*)malloc(sizeof(keyed) * nn);
+        keyed* ks = (keyed*)malloc(sizeof(keyed) * (size_t)max_row);
+#pragma omp for schedule(dynamic, 256)
         for (int32_t u = 0; u < m->U; ++u) {
             int64_t b = m->u_ptr[u], e = m->u_ptr[u + 1];
             for (int64_t p = b; p < e; ++p) {
@@ -326,6 +373,7 @@ orc_model* orc_fit(const int32_t* users, const int32_t* items, const double* rat
         }
         free(ks);
     }
+#pragma omp parallel for schedule(static)
     for (int64_t t = 0; t < n; ++t) {
         double w = m->weight[m->du[t]];
         m->pre[t] = (w != 0) ? m->dev[t] / w : 0.0;
@@ -336,8 +384,10 @@ orc_model* orc_fit(const int32_t* users, const int32_t* items, const double* rat
      * getItemsAvgDev :336-343 (Spark): reduceByKey, modelled in file order. */
     m->item_avg_dev = (double*)malloc(sizeof(double) * (size_t)(m->I > 0 ? m->I : 1));
     m->item_avg_dev_spark = (double*)malloc(sizeof(double) * (size_t)(m->I > 0 ? m->I : 1));
+#pragma omp parallel
     {
-        keyed* ks = (keyed*)malloc(sizeof(keyed) * nn);
+        keyed* ks = (keyed*)malloc(sizeof(keyed) * (size_t)max_col);
+#pragma omp for schedule(dynamic, 16)
         for (int32_t i = 0; i < m->I; ++i) {
             int64_t b = m->i_ptr[i], e = m->i_ptr[i + 1];
             double sf = 0.0;
@@ -1193,6 +1243,16 @@ double orc_knn_table_predict(const orc_knn_table* t, const int32_t* users, const
         for (int64_t r = 0; r < n; ++r) s = fabs(ratings[r] - out_pred[r]) + s;
     free(du); free(ptr); free(rows);
     return ratings ? s / (double)n : 0.0;
+}
+
+/* caps the threads of every later OpenMP region of this library (orc_fit's per-user / per-item loops and the bulk form);
+ * n <= 0 restores the default (all cores) */
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n > 0 ? n : omp_get_num_procs());
+#else
+    (void)n;
+#endif
 }
 
 int orc_max_threads(void) {

@@ -145,6 +145,7 @@ void orc_knn_table_export_ids(const orc_knn_table*, int32_t* out_ids /*[rows*wid
 double orc_knn_table_predict(const orc_knn_table*, const int32_t* users, const int32_t* items, const double* ratings,
                              int64_t n, int threads, double* out_pred, int* status);
 int orc_max_threads(void);
+void orc_set_threads(int n); /* cap for orc_fit's parallel loops and the bulk form; <= 0: all cores */
 
 #ifdef __cplusplus
 }

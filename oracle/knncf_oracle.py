@@ -111,6 +111,8 @@ def lib():
     L.orc_knn_table_predict.restype = C.c_double
     L.orc_knn_table_predict.argtypes = [C.c_void_p, _i32p, _i32p, _f64p, C.c_int64, C.c_int, _f64p, C.POINTER(C.c_int)]
     L.orc_max_threads.restype = C.c_int
+    L.orc_set_threads.restype = None
+    L.orc_set_threads.argtypes = [C.c_int]
     _lib = L
     return L
 
@@ -247,6 +249,11 @@ class Model:
     def knn_table(self, k, users=None, threads=0):
         """The kNN closures (cosine, k) for many users at once on all cores (every user when users is None)."""
         return KnnTable(self, k, users, threads)
+
+
+def set_threads(n):
+    """cap the threads of orc_fit's parallel loops and of the bulk form (n <= 0: all cores)"""
+    lib().orc_set_threads(int(n))
 
 
 def host_threads(cap=64):
