@@ -313,7 +313,7 @@ void build_neighbors(knncf_handle* h, int32_t count) {
                                                 : (int64_t)std::min<size_t>((size_t)48 << 30, (free_b + held) / 4);
     const int64_t s_elem = s_fp16 ? 2 : 4;
     // per panel row: the similarity row, the operand row, the shortlist store and the provisional group store
-    int64_t per_row = U_pad * s_elem + K_pad * 2 + (int64_t)shortlist_cap(nt.k, tr.U) * 8 + (int64_t)SELECT_GCAP * 36;
+    int64_t per_row = U_pad * s_elem + K_pad * 2 + (int64_t)shortlist_cap(nt.k, tr.U) * 8 + (int64_t)select_gcap(nt.k) * 36;
     int64_t R = std::max<int64_t>(256, (budget / per_row) / 256 * 256);
     R = std::min<int64_t>(R, round_up(count, 256));
     const int64_t n_blocks = ceil_div(count, R);
@@ -333,8 +333,8 @@ void build_neighbors(knncf_handle* h, int32_t count) {
     h->sel.cand_cnt.ensure(R);
     h->sel.cand_eps.ensure(R);
     h->sel.row_entries.ensure(R);
-    h->sel.grp_v0.ensure((size_t)R * SELECT_GCAP);
-    h->sel.grp_x.ensure((size_t)R * SELECT_GCAP * 8);
+    h->sel.grp_v0.ensure((size_t)R * select_gcap(nt.k));
+    h->sel.grp_x.ensure((size_t)R * select_gcap(nt.k) * 8);
     h->sel.stats.ensure(4);
     KN_HIP(hipMemsetAsync(h->sel.stats.p, 0, 4 * sizeof(double), st));  // [0] bound check, [1] candidate row entries
     if (h->pinned_cap < (size_t)count) {
@@ -380,7 +380,7 @@ void build_neighbors(knncf_handle* h, int32_t count) {
             // sparse tail (LDS atomics per row tile) + histogram select, fused: one pass over S
             Stage s(h, &h->tm.select_ms, sc);
             launch_tail_select(tr, h->colmap.p, head < tr.I, h->S[slot].p, s_fp16, U_pad, rows, d_rows, nt.k, eps_opnd, eps_rest, cap,
-                               h->sel.cand_idx.p, h->sel.cand_approx.p, h->sel.cand_cnt.p, h->sel.cand_eps.p, h->sel.grp_v0.p, h->sel.grp_x.p, sc);
+                               h->sel.cand_idx.p, h->sel.cand_approx.p, h->sel.cand_cnt.p, h->sel.cand_eps.p, h->sel.grp_v0.p, h->sel.grp_x.p, select_gcap(nt.k), sc);
             h->tm.tail_pair_updates += h->tail_pairs_full * ((double)rows / (double)tr.U);
             h->tm.select_row_bytes += (double)s_elem * (double)rows * (double)tr.U;
         }

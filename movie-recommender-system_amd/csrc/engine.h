@@ -12,8 +12,8 @@ namespace knncf {
 typedef __bf16 bf16_t;
 
 // columns of a similarity row that select.hip holds in LDS at a time (prep.hip tabulates the tile crossings)
-// provisional store of select.hip per similarity row: groups of 8 columns (36 B each)
-static constexpr int SELECT_GCAP = 8192;
+// provisional store of select.hip per similarity row: groups of 8 columns (36 B each); the capacity scales with k
+inline int32_t select_gcap(int32_t k) { return 8192 * (int32_t)((k + 511) / 512 > 1 ? (k + 511) / 512 : 1); }
 static constexpr int SELECT_TCOLS = 16384;  // <= 2^15: it_pack keeps the LDS cell of the column inside its tile in 15 bits
 
 // ---- sort_util.hip (rocPRIM device radix sort / unique; K0 plumbing only) ---------------
@@ -133,8 +133,8 @@ struct SelectScratch {
     DArr<float> cand_approx;  // [rows * cap] (KNNCF_FLAG_VERIFY_BOUND)
     DArr<int32_t> cand_cnt;   // [rows] (> cap == overflow)
     DArr<float> cand_eps;     // [rows] the error band of the row's approximate similarities
-    DArr<int32_t> grp_v0;     // [rows * SELECT_GCAP] provisional groups: first column
-    DArr<float> grp_x;        // [rows * SELECT_GCAP * 8] their 8 values
+    DArr<int32_t> grp_v0;     // [rows * select_gcap(k)] provisional groups: first column
+    DArr<float> grp_x;        // [rows * select_gcap(k) * 8] their 8 values
     DArr<double> stats;       // [4]: max bound violation, ...
     DArr<uint32_t> row_entries;  // [rows] ratings of the row's shortlisted candidates (re-rank traffic accounting)
     DArr<double> row_exact;   // fallback: [U] exact similarities of one row
@@ -147,7 +147,7 @@ struct SelectScratch {
 void launch_tail_select(const Train& tr, const int32_t* d_colmap, bool has_tail, const void* S, bool s_fp16, int64_t lds,
                         int32_t n_rows, const int32_t* d_row_user, int32_t k, float eps_opnd, float eps_rest, int32_t cap,
                         int32_t* cand_idx, float* cand_approx, int32_t* cand_cnt, float* cand_eps, int32_t* grp_v0, float* grp_x,
-                        hipStream_t st);
+                        int32_t gcap, hipStream_t st);
 // exact fp64 similarities of the shortlists in reference order, stable top-k
 void launch_rerank(const Train& tr, NeighborTable& nt, int32_t n_rows, const int32_t* d_row_user,
                    int32_t cap, const int32_t* cand_idx, const float* cand_approx,

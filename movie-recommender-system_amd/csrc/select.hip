@@ -9,15 +9,17 @@
 //      are sorted by user and prep.hip tabulates where each list crosses a tile boundary (it_tile), so the
 //      tile's work is a set of [begin, end) ranges; they are cut into 64-rater pieces and the pieces are
 //      dealt evenly to the 8 waves (a prefix sum over the entries), several pieces in flight per wave;
-//   2. the tile's final values S + tail stay in registers and enter a cumulative 4096-bin LDS histogram;
-//      the bin holding the k-th largest value SEEN SO FAR gives a threshold that can only rise as more
-//      columns are seen, so every v of the tile with value >= (bin lower edge - 2 eps) is appended to a
-//      provisional shortlist;
-//   3. after the last tile the threshold is final and the provisional list is compacted in place.
+//   2. the tile's final values S + tail stay in registers; every GROUP of 8 columns whose maximum reaches the
+//      threshold known so far is stored whole in a per-row provisional store in global memory (gcap groups, scaled with
+//      k).  The threshold — lower edge of the bin that holds the k-th largest value of a 1024-bin histogram, minus 2 eps —
+//      is bootstrapped from the first tile and refreshed from the stored values (after tiles 1, 3, 6 and whenever the
+//      store has grown); it can only rise, so a stale one merely lets more through;
+//   3. after the last tile the threshold is final and the stored values are sorted out once into the shortlist.
 // With |S[u][v] - s_uv| <= eps for every pair, every true top-k member v satisfies
 // S[u][v] >= a_k - 2 eps (a_k = k-th largest value of the row), so the shortlist provably contains
-// the exact top-k; rerank.hip decides.  HBM-bound: S is read exactly once and never written back; the
-// tail's per-pair products never touch HBM atomics.
+// the exact top-k; rerank.hip decides.  The panel S is read exactly once (it was written by the GEMM: the round trip
+// through HBM is the cost of keeping GEMM and select separate kernels); the kernel itself is bound by
+// VALU issue in the tail drain, not by that traffic.
 #include <math.h>
 
 #include <type_traits>
@@ -42,7 +44,6 @@ __device__ unsigned long long g_phase[16];
 // __launch_bounds__(2 * TPB) caps the kernel at 128 VGPRs so that both workgroups fit.
 static constexpr int TPB = 512;
 static constexpr int NBINS = 1024;
-static constexpr int GCAP = SELECT_GCAP;  // provisional groups per row
 static constexpr int TCOLS = SELECT_TCOLS;  // columns of the row held in LDS at a time (64 KiB)
 static constexpr int CPT = TCOLS / TPB;  // columns per thread per tile (32 = 4 groups of 8)
 static constexpr int NG = CPT / 8;
@@ -165,7 +166,7 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
                                                      int32_t kk, float eps_opnd, float eps_rest, int32_t cap, int32_t* __restrict__ cand_idx,
                                                      float* __restrict__ cand_approx, int32_t* __restrict__ cand_cnt,
                                                      float* __restrict__ cand_eps, int32_t* __restrict__ grp_v0,
-                                                     float* __restrict__ grp_x) {
+                                                     float* __restrict__ grp_x, int32_t GCAP) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int32_t* itile = reinterpret_cast<int32_t*>(smem);            // [TCOLS] tail accumulator, Q7.24, cell layout of it_pack
     uint32_t* hist = reinterpret_cast<uint32_t*>(itile + TCOLS);  // [NBINS]
@@ -446,6 +447,7 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
     };
     PH(0);  // preamble: collect, clears
     int tile_no = 0;
+    uint32_t next_refresh = (uint32_t)GCAP / 4;  // store level that triggers an extra threshold refresh (block-uniform)
     for (int32_t t0 = 0; t0 < U; t0 += TCOLS, ++tile_no) {
         if (pipelined) {
             use_tables(tile_no & 1);
@@ -590,9 +592,10 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
         // the store is filling up (wide error bands, e.g. bf16 operands)
         {
             const uint32_t prov = s_count;  // (block-uniform after the barrier)
-            if ((tile_no == 1 || tile_no == 3 || tile_no == 6 || prov > (uint32_t)GCAP / 4) && prov <= (uint32_t)GCAP && t0 + TCOLS < U) {
+            if ((tile_no == 1 || tile_no == 3 || tile_no == 6 || prov > next_refresh) && prov <= (uint32_t)GCAP && t0 + TCOLS < U) {
                 rebuild_hist(s_thr);
                 block_threshold(hist, wtot, &s_thr, kk, eps);
+                next_refresh = max(next_refresh, prov + (uint32_t)GCAP / 8);  // (the store is not compacted: refresh again only after it has grown)
             }
         }
     }
@@ -665,11 +668,11 @@ void select_profile_dump() {
 template <class ST>
 static void launch_tail_select_t(const TailArgs& T, const ST* S, int64_t lds, int32_t n_rows, const int32_t* d_row_user,
                                  int32_t U, int32_t kk, float eps_opnd, float eps_rest, int32_t cap, int32_t* cand_idx, float* cand_approx,
-                                 int32_t* cand_cnt, float* cand_eps, int32_t* grp_v0, float* grp_x, hipStream_t st) {
+                                 int32_t* cand_cnt, float* cand_eps, int32_t* grp_v0, float* grp_x, int32_t gcap, hipStream_t st) {
     const size_t smem = (size_t)TCOLS * 4 + (size_t)NBINS * 4 + (size_t)EMAX * 4 + 2 * ((size_t)EMAX * 12 + (size_t)PMAX * 2) + (2 * (TPB / 64) + 4 + 64) * 4;  // + 64 scratch cells
     static PerDeviceState lds_state;
     ensure_dynamic_lds(lds_state, (const void*)k_tail_select<ST>, smem);
-    k_tail_select<ST><<<n_rows, TPB, smem, st>>>(S, lds, n_rows, d_row_user, T, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x);
+    k_tail_select<ST><<<n_rows, TPB, smem, st>>>(S, lds, n_rows, d_row_user, T, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap);
     KN_HIP(hipGetLastError());
 #ifdef KNNCF_SELECT_PROFILE
     KN_HIP(hipStreamSynchronize(st));
@@ -680,15 +683,16 @@ static void launch_tail_select_t(const TailArgs& T, const ST* S, int64_t lds, in
 void launch_tail_select(const Train& tr, const int32_t* d_colmap, bool has_tail, const void* S, bool s_fp16, int64_t lds,
                         int32_t n_rows, const int32_t* d_row_user, int32_t k, float eps_opnd, float eps_rest, int32_t cap,
                         int32_t* cand_idx, float* cand_approx, int32_t* cand_cnt, float* cand_eps, int32_t* grp_v0, float* grp_x,
-                        hipStream_t st) {
+                        int32_t gcap, hipStream_t st) {
     if (n_rows <= 0) return;
+    KN_REQUIRE(gcap >= 1024 && gcap % 8 == 0, KNNCF_E_INVALID, "select: group store too small");
     const int32_t U = tr.U;
     int32_t kk = k < U - 1 ? k : U - 1;
     if (kk < 1) kk = 1;
     KN_REQUIRE(!has_tail || tr.tile_stride == (int32_t)ceil_div(U, TCOLS) + 1, KNNCF_E_STATE, "select: tile table missing");
     TailArgs T{tr.u_ptr.p, tr.s_col.p, tr.s_pre.p, d_colmap, tr.i_ptr.p, tr.it_pack.p, (uint32_t)(tr.n * 4), tr.it_tile.p, tr.tile_stride, has_tail ? 1 : 0};
-    if (s_fp16) launch_tail_select_t(T, static_cast<const _Float16*>(S), lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, st);
-    else launch_tail_select_t(T, static_cast<const float*>(S), lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, st);
+    if (s_fp16) launch_tail_select_t(T, static_cast<const _Float16*>(S), lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, st);
+    else launch_tail_select_t(T, static_cast<const float*>(S), lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, st);
 }
 
 }  // namespace knncf
