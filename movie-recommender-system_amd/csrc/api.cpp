@@ -216,7 +216,9 @@ float gemm_eps_operand(bool fp16) {
 float gemm_eps_rest(bool fp16) {
     // the tail's fp32 operand/product roundings (3 * 2^-24 of sum |x y| <= 1); fp16: |pre| <= 1, below 2^-14 the
     // grid is absolute, 2^-25 per operand: sum (|x| + |y|) 2^-25 <= 2 sqrt(n) 2^-25 < 6e-6 for n < 10^4
-    return (float)(4e-7 + (fp16 ? 6e-6 : 0.0));
+    // + the tail's row-side factor travels with its 6 low mantissa bits replaced (select.hip: piece descriptors):
+    //   relative 2^-17 of sum |x y| <= 1
+    return (float)(4e-7 + (fp16 ? 6e-6 : 0.0) + 8e-6);
 }
 
 // per-row shortlist storage: rows whose error band holds more candidates than this take the exact

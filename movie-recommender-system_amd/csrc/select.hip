@@ -51,7 +51,7 @@ static_assert(CPT <= 32, "the survivor mask of a thread is one 32-bit word");
 static constexpr int EMAX = 256;     // row positions whose tail entries (16 B each) are held in LDS at a time
 static constexpr int PMAX = 1024;    // pieces per (chunk, tile) with a direct piece -> entry table in LDS
 static constexpr int MAXT = 16;      // tiles whose per-entry rater counts are packed into registers
-static constexpr int TAIL_ILP = 16;        // 64-rater pieces a wave keeps in flight
+static constexpr int TAIL_G = 8;           // pieces per group of the drain (two groups in flight per wave)
 // the tail is accumulated in Q7.24 fixed point with integer LDS atomics (ds_add_u32; the float form
 // ds_add_f32 measured ~1.4x slower here): |sum| <= 1, each product is quantised with error <= 2^-25,
 // which the per-common-item term of row_eps covers.  The rater-side factor comes as Q0.16 (4-byte tail
@@ -187,6 +187,7 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
     float& s_thr = *reinterpret_cast<float*>(wtot + TPB / 64);
     uint32_t& s_count = wtot[TPB / 64 + 1];
     int32_t& s_ne = *reinterpret_cast<int32_t*>(wtot + TPB / 64 + 2);
+    uint32_t& s_next = wtot2[TPB / 64];  // (first of the 64 spare cells behind wtot2) next undealt piece of the tile
     const int32_t r = blockIdx.x;
     if (r >= n_rows) return;
 #ifdef KNNCF_SELECT_PROFILE
@@ -290,13 +291,14 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
     __syncthreads();  // also: every owner has read e_item before e_ps (its alias) is written
 
     // ---- the tail machinery: setup (ranges, prefix, piece table) / window (piece descriptors of up to 64 pieces of
-    // this wave) / issue (TAIL_ILP piece loads) / apply (their LDS atomics) ---------------------------------------
-    constexpr int ILP = sizeof(ST) == 2 ? TAIL_ILP : TAIL_ILP / 2;  // fp32 panels hold twice the prefetch registers
+    // this wave) / tail_group (TAIL_G piece loads and their LDS atomics) ------------------------------------------
     uint32_t P = 0, p_lo = 0, p_hi = 0, n_here = 0;
     int32_t ne = 0;
-    uint32_t d_q = 0, d_end = 0;
-    float d_x = 0.f;
-    uint32_t w[ILP];
+    // piece descriptors of a window, one piece per lane: d_q = first entry of the piece, d_xs = the row-side factor
+    // pre(u, item) * 2^8 as fp32 with its 6 low mantissa bits replaced by (64 - entries of the piece): the word is used
+    // as the multiplier as it is (|relative error| < 2^-17, inside the row's error band: api.cpp gemm_eps_rest) and as the
+    // shift count of the piece's lane mask (s_lshr_b64 reads the low 6 bits only)
+    uint32_t d_q = 0, d_xs = 0;
     // setup of a tile = two halves around ONE barrier: (a) every entry's range inside the tile and the piece counts per
     // wave, (b) the exclusive prefix, the piece -> entry table and this wave's share [p_lo, p_hi) of the pieces.
     // `buf` selects the table copy.  For single-chunk rows the halves of tile t + 1 sit around a barrier tile t needs
@@ -343,12 +345,19 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
                 for (uint32_t k2 = 0; k2 < su_np; ++k2) piece_e0[buf * PMAX + excl + k2] = (uint16_t)threadIdx.x;
         }
         // the pieces are dealt evenly: wave w takes [p_lo, p_hi).  (wave-uniform values are moved to scalar registers
-        // explicitly: the loops below then run on the scalar unit and the lane broadcasts are v_readlane)
+        // explicitly: the loops below then run on the scalar unit)
         P = __builtin_amdgcn_readfirstlane(P);
         ne = __builtin_amdgcn_readfirstlane(ne);
         const uint32_t wv = __builtin_amdgcn_readfirstlane(wave);
         p_lo = (uint32_t)(((uint64_t)P * wv) / (TPB / 64));
         p_hi = (uint32_t)(((uint64_t)P * (wv + 1)) / (TPB / 64));
+#ifdef KNNCF_SEL_DYNAMIC
+        // dynamic dealing: the waves take windows of KNNCF_SEL_DYNAMIC pieces off a shared counter (reset here, between the
+        // barrier that ends the previous drain and the one that opens the next)
+        if (threadIdx.x == 0) s_next = 0;
+        p_lo = 0;
+        p_hi = P;
+#endif
     };
     auto use_tables = [&](int buf) {
         e_b = e_b0 + buf * EMAX;
@@ -356,9 +365,16 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
         e_ps = e_ps0 + buf * EMAX;
         piece_e = piece_e0 + buf * PMAX;
     };
-    auto window = [&](uint32_t pw) {  // lane l looks up the entry of piece pw + l and keeps its range
+    auto window = [&](uint32_t pw) {  // lane l looks up the entry of piece pw + l and keeps its descriptor
+#ifdef KNNCF_SEL_DYNAMIC
+        n_here = min((uint32_t)KNNCF_SEL_DYNAMIC, p_hi - pw);
+#else
         n_here = min(64u, p_hi - pw);
-        d_q = 0; d_end = 0; d_x = 0.f;
+#endif
+        // lanes past the window's pieces hold a NULL piece (one lane, factor 0.0: it adds 0 to the cell of entry 0), so
+        // that the drain below only ever runs whole groups
+        d_q = 0;
+        d_xs = 63u;
         if ((uint32_t)lane < n_here) {
             const uint32_t p2 = pw + lane;
             int32_t e;
@@ -374,55 +390,125 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
                 e = lo;
             }
             d_q = e_b[e] + ((p2 - e_ps[e]) << 6);
-            d_end = e_e[e];
-            d_x = e_x[e];
+            const uint32_t len = min(64u, e_e[e] - d_q);  // 1 .. 64
+            d_xs = (__float_as_uint(e_x[e]) & ~63u) | (64u - len);
         }
     };
-    // the entries come through a buffer descriptor: 32-bit offsets, and a lane outside its piece gets offset ~0, which
-    // the range check answers with 0 — a word that adds nothing, so "w != 0" is the only predicate
-    const __amdgpu_buffer_rsrc_t pack_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(T.it_pack), 0, T.pack_bytes, 0x00020000);
-    // (this loop is the kernel's VALU bottleneck — SQ counters: 78 % VALU issue utilisation — so instructions are
-    // counted: the lane's byte offset is precomputed, the piece's start comes as a scalar, and the LDS atomic takes the
-    // cell's byte address as is — the accumulator sits at LDS address 0)
-    typedef __attribute__((address_space(3))) int32_t* lds_i32;
-    // a lane without an entry (the tail of a piece) adds 0 to a scratch cell of its own instead of being branched around:
-    // besides VALU, the loop is bound by the CU's single scalar unit (SQ counters), and a branch costs three scalar ops
-    const uint32_t dummy_addr = (uint32_t)(reinterpret_cast<char*>(wtot2 + TPB / 64) - smem) + ((uint32_t)lane << 2);
-    // FULL: all ILP pieces exist (no per-piece bound check); otherwise pieces past n_here get an empty range
-    auto issue = [&](uint32_t j0, auto full) {
-        constexpr bool FULL = decltype(full)::value;
-#pragma unroll
-        for (int j = 0; j < ILP; ++j) {
-            const int src = FULL ? (int)(j0 + j) : (int)min(j0 + j, 63u);  // wave-uniform
-            const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane((int)d_q, src);
-            const uint32_t len = (FULL || j0 + j < n_here) ? (uint32_t)__builtin_amdgcn_readlane((int)d_end, src) - q0 : 0u;  // scalar
-            w[j] = __builtin_amdgcn_raw_buffer_load_b32(pack_rsrc, (uint32_t)lane < len ? (int)((q0 + lane) << 2) : -1, 0, 0);
-        }
+    // The drain: the pieces of a window (<= 64, 8 to a group), as ONE hand-scheduled asm statement per window.  A piece is
+    // one 64-lane load of 4-byte tail entries and one LDS-atomic instruction.  Written to the instruction: per piece 8 VALU
+    // (two v_readlane for the piece's start and factor, sign-extract / convert / multiply / convert of the Q0.16 rater-side
+    // value, two for the cell's byte address — the accumulator sits at LDS address 0 and the cell comes out of it_pack
+    // ready-made), 5 SALU, one buffer load, one ds_add.  The compiler's version of the same loop took 14 VALU per piece:
+    // it paid a compare and a select per piece on both sides to keep lanes past the end of a piece harmless; here the
+    // loads run unmasked (the entries behind a piece's end are mapped memory: the buffer descriptor covers the whole array
+    // and answers 0 beyond it) and the atomics run under the piece's lane mask, set from the scalar unit
+    // (s_lshr_b64 exec, -1, 64 - len).  Measured (syn-25m, timing-only ablations): of the kernel's 35.6 ms,
+    // the drain is 14.6 — 6.2 of them its loads and atomics, 8.4 instruction issue — and the rest of the tail machinery 4.4.
+    // Counting by hand (cdna_hip_programming.md 5.7): every apply waits for its own load with vmcnt(15 - j): a whole
+    // younger group is in flight behind it.  Any older load or store of the wave (the next tile's panel entries, the last
+    // tile's group stores) retires first, in order, so the count only ever over-waits; the statement ends with vmcnt(0).
+    // The ds_adds need no wait (no return value; the tile's barrier drains lgkmcnt).  EXEC is all ones on entry
+    // (wave-uniform control flow, 512-thread blocks) and is restored after every atomic.  Hazards (hipcc pads nothing inside
+    // the string): every SGPR a buffer_load or a v_readlane lane-select reads is written by the scalar unit (s_lshl /
+    // s_add), never directly by a VALU; the factor's v_readlane is three instructions ahead of the v_mul that reads its
+    // SGPR (gfx940 family: 2 wait states); SALU writes of EXEC need no wait states before VMEM / LDS; s_add / s_lshl /
+    // s_cmp write SCC (declared).
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+    // raw buffer descriptor of it_pack (stride 0: byte offsets, range-checked against the array's size; the same words
+    // __builtin_amdgcn_make_buffer_rsrc(it_pack, 0, pack_bytes, 0x00020000) builds)
+    const uint64_t pack_base = reinterpret_cast<uint64_t>(T.it_pack);
+    const u32x4 pack_rsrc = {(uint32_t)pack_base, (uint32_t)(pack_base >> 32) & 0xffffu, T.pack_bytes, 0x00020000u};
+    const uint32_t lane4 = (uint32_t)lane << 2;
+#ifdef KNNCF_ABL_NOLOAD  /* timing-only ablations (results are wrong): what the drain costs without its loads / atomics */
+#define KN_TAIL_LOAD(W) "v_mov_b32 %[" W "], %[l4]\n\t"
+#else
+#define KN_TAIL_LOAD(W) "buffer_load_dword %[" W "], %[l4], %[rs], %[sq] offen\n\t"
+#endif
+#ifdef KNNCF_ABL_NOATOMIC
+#define KN_TAIL_ADD "s_nop 0\n\t"
+#else
+#define KN_TAIL_ADD "ds_add_u32 %[a], %[t]\n\t"
+#endif
+// piece (group base %[sg]) + OFF: start of the piece -> byte offset in a scalar, the load of its 64 entries into W
+#define KN_TAIL_ISSUE(W, OFF)                                              \
+    "s_add_u32 %[sj], %[sg], " #OFF "\n\t"                                 \
+    "v_readlane_b32 %[sq], %[dq], %[sj]\n\t"                               \
+    "s_lshl_b32 %[sq], %[sq], 2\n\t"                                       \
+    KN_TAIL_LOAD(W)
+// piece (group base %[sg]) + OFF: wait until at most N younger loads are in flight, products, cell addresses, the atomics
+// under the piece's lane mask
+#define KN_TAIL_APPLY(W, OFF, N)                                           \
+    "s_add_u32 %[sj], %[sg], " #OFF "\n\t"                                 \
+    "v_readlane_b32 %[sx], %[dx], %[sj]\n\t"                               \
+    "s_waitcnt vmcnt(" #N ")\n\t"                                          \
+    "v_bfe_i32 %[t], %[" W "], 0, 17\n\t"                                  \
+    "v_cvt_f32_i32_e32 %[t], %[t]\n\t"                                     \
+    "v_mul_f32_e32 %[t], %[sx], %[t]\n\t"                                  \
+    "v_cvt_i32_f32_e32 %[t], %[t]\n\t"                                     \
+    "v_lshrrev_b32_e32 %[a], 15, %[" W "]\n\t"                             \
+    "v_and_b32_e32 %[a], 0x1fffc, %[a]\n\t"                                \
+    "s_lshr_b64 exec, -1, %[sx]\n\t"                                       \
+    KN_TAIL_ADD                                                            \
+    "s_mov_b64 exec, -1\n\t"
+#define KN_TAIL_ISSUE8(S, B)                                                                                       \
+    KN_TAIL_ISSUE(S "0", B + 0) KN_TAIL_ISSUE(S "1", B + 1) KN_TAIL_ISSUE(S "2", B + 2) KN_TAIL_ISSUE(S "3", B + 3) \
+    KN_TAIL_ISSUE(S "4", B + 4) KN_TAIL_ISSUE(S "5", B + 5) KN_TAIL_ISSUE(S "6", B + 6) KN_TAIL_ISSUE(S "7", B + 7)
+#define KN_TAIL_APPLY8(S)                                                                                          \
+    KN_TAIL_APPLY(S "0", 0, 15) KN_TAIL_APPLY(S "1", 1, 14) KN_TAIL_APPLY(S "2", 2, 13) KN_TAIL_APPLY(S "3", 3, 12) \
+    KN_TAIL_APPLY(S "4", 4, 11) KN_TAIL_APPLY(S "5", 5, 10) KN_TAIL_APPLY(S "6", 6, 9) KN_TAIL_APPLY(S "7", 7, 8)
+    // all groups of a window (n8 = its pieces rounded up to whole groups, 8 .. 64), software-pipelined two groups deep:
+    // group g + 1's loads are issued before group g's atomics, into the other register set (A / B alternate, the loop is
+    // unrolled twice).  A next group is ALWAYS issued — past the window's end it re-reads the descriptors of lanes 0 .. 7
+    // (v_readlane takes the lane select modulo 64): mapped memory, never applied — so that the vmcnt counts are the same
+    // for every group; the final vmcnt(0) retires that last, unused group before the registers go back to the compiler.
+    auto tail_window = [&](uint32_t n8) {
+        uint32_t a0, a1, a2, a3, a4, a5, a6, a7, b0, b1, b2, b3, b4, b5, b6, b7, t, a, sq, sx, sj, sg;
+        asm volatile(
+            "s_mov_b32 %[sg], 0\n\t"
+            KN_TAIL_ISSUE8("a", 0)
+            "1:\n\t"
+            KN_TAIL_ISSUE8("b", 8)
+            KN_TAIL_APPLY8("a")
+            "s_add_u32 %[sg], %[sg], 8\n\t"
+            "s_cmp_ge_u32 %[sg], %[n8]\n\t"
+            "s_cbranch_scc1 2f\n\t"
+            KN_TAIL_ISSUE8("a", 8)
+            KN_TAIL_APPLY8("b")
+            "s_add_u32 %[sg], %[sg], 8\n\t"
+            "s_cmp_lt_u32 %[sg], %[n8]\n\t"
+            "s_cbranch_scc1 1b\n\t"
+            "2:\n\t"
+            "s_waitcnt vmcnt(0)\n\t"
+            : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [a4] "=&v"(a4), [a5] "=&v"(a5), [a6] "=&v"(a6),
+              [a7] "=&v"(a7), [b0] "=&v"(b0), [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3), [b4] "=&v"(b4), [b5] "=&v"(b5),
+              [b6] "=&v"(b6), [b7] "=&v"(b7), [t] "=&v"(t), [a] "=&v"(a), [sq] "=&s"(sq), [sx] "=&s"(sx), [sj] "=&s"(sj),
+              [sg] "=&s"(sg)
+            : [dq] "v"(d_q), [dx] "v"(d_xs), [n8] "s"(n8), [l4] "v"(lane4), [rs] "s"(pack_rsrc)
+            : "memory", "scc");
     };
-    auto apply = [&](uint32_t j0, auto full) {
-        constexpr bool FULL = decltype(full)::value;
-#pragma unroll
-        for (int j = 0; j < ILP; ++j) {
-            const float xf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d_x), FULL ? (int)(j0 + j) : (int)min(j0 + j, 63u)));
-            const int32_t qv = ((int32_t)(w[j] << 15)) >> 15;  // sign-extended low 17 bits (0 for a lane without an entry)
-            const uint32_t addr = w[j] != 0u ? ((w[j] >> 15) & 0x1fffcu) : dummy_addr;
-            // truncation: < 2^-24, inside row_eps' per-item term
-            __atomic_fetch_add((lds_i32)(uintptr_t)addr, (int32_t)(xf * (float)qv), __ATOMIC_RELAXED);
-        }
-    };
+#undef KN_TAIL_ISSUE8
+#undef KN_TAIL_APPLY8
+#undef KN_TAIL_ISSUE
+#undef KN_TAIL_APPLY
     auto drain = [&](bool) {
+#ifdef KNNCF_ABL_NODRAIN  /* timing-only ablation: everything but the drain itself */
+        return;
+#endif
+#ifdef KNNCF_SEL_DYNAMIC
+        for (;;) {
+            uint32_t pw = 0;
+            if (lane == 0) pw = atomicAdd(&s_next, (uint32_t)KNNCF_SEL_DYNAMIC);
+            pw = __builtin_amdgcn_readfirstlane(pw);
+            if (pw >= p_hi) break;
+            window(pw);
+            tail_window(__builtin_amdgcn_readfirstlane((n_here + 7u) & ~7u));
+        }
+#else
         for (uint32_t pw = p_lo; pw < p_hi; pw += 64) {
             window(pw);
-            uint32_t j0 = 0;
-            for (; j0 + ILP <= n_here; j0 += ILP) {
-                issue(j0, std::true_type{});
-                apply(j0, std::true_type{});
-            }
-            if (j0 < n_here) {
-                issue(j0, std::false_type{});
-                apply(j0, std::false_type{});
-            }
+            tail_window(__builtin_amdgcn_readfirstlane((n_here + 7u) & ~7u));
         }
+#endif
     };
     const bool pipelined = any_tail && n_chunks == 1;  // single-chunk rows: tile t + 1 is set up inside tile t
     if (pipelined) {
@@ -592,7 +678,11 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
         // the store is filling up (wide error bands, e.g. bf16 operands)
         {
             const uint32_t prov = s_count;  // (block-uniform after the barrier)
+#ifdef KNNCF_SEL_NOREFRESH
+            if (prov > next_refresh && prov <= (uint32_t)GCAP && t0 + TCOLS < U) {
+#else
             if ((tile_no == 1 || tile_no == 3 || tile_no == 6 || prov > next_refresh) && prov <= (uint32_t)GCAP && t0 + TCOLS < U) {
+#endif
                 rebuild_hist(s_thr);
                 block_threshold(hist, wtot, &s_thr, kk, eps);
                 next_refresh = max(next_refresh, prov + (uint32_t)GCAP / 8);  // (the store is not compacted: refresh again only after it has grown)
@@ -690,6 +780,10 @@ void launch_tail_select(const Train& tr, const int32_t* d_colmap, bool has_tail,
     int32_t kk = k < U - 1 ? k : U - 1;
     if (kk < 1) kk = 1;
     KN_REQUIRE(!has_tail || tr.tile_stride == (int32_t)ceil_div(U, TCOLS) + 1, KNNCF_E_STATE, "select: tile table missing");
+    // (KNNCF_DEBUG_SKIP_TAIL: timing-only hook — drops the sparse tail, so the neighbours are WRONG; it measures what the
+    // kernel costs without the tail machinery: the panel scan, the thresholds, the group store)
+    static const bool skip_tail = getenv("KNNCF_DEBUG_SKIP_TAIL") != nullptr;
+    if (skip_tail) has_tail = false;
     TailArgs T{tr.u_ptr.p, tr.s_col.p, tr.s_pre.p, d_colmap, tr.i_ptr.p, tr.it_pack.p, (uint32_t)(tr.n * 4), tr.it_tile.p, tr.tile_stride, has_tail ? 1 : 0};
     if (s_fp16) launch_tail_select_t(T, static_cast<const _Float16*>(S), lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, st);
     else launch_tail_select_t(T, static_cast<const float*>(S), lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, st);
