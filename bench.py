@@ -212,7 +212,8 @@ def main():
         steps = max(1, args.steps)
         n_test = len(te)
         ms_per_step = elapsed / steps * 1e3
-        launches = max(1, tm["gemm_launches"])  # every per-row-block kernel is launched once per GEMM launch
+        gemm_launches = max(1, tm["gemm_launches"])          # ONE per neighbour build on the symmetric path, else one per row block
+        launches = max(1, tm["select_launches"])              # row-block launches of select / re-rank
         k = args.k
 
         # Cache/HBM-side traffic per launch from the committed PMC passes of this workload (rocprofv3 --pmc FETCH_SIZE /
@@ -244,7 +245,7 @@ def main():
             "k_gemm_nt_bf16": roof("k_gemm_nt_bf16 (user x user similarity, dense head, MFMA)", "mfma", tm["gemm_ms"],
                                    0.5 * tm["gemm_flops_algorithmic"], MFMA_BF16_DENSE_PEAK_TFLOPS, "TFLOP/s",
                                    "rows * (U-1) * head_items flops per launch = each unordered (row, user) pair once x 2 flops x head_items "
-                                   "(SURVEY 8d with I_c -> the dense head; the sparse tail is k_tail_select's work)", key="k_gemm_nt_bf16"),
+                                   "(SURVEY 8d with I_c -> the dense head; the sparse tail is k_tail_select's work)", launches=gemm_launches, key="k_gemm_nt_bf16"),
             # compulsory HBM bytes: the similarity panel is read once, the 4-byte tail entries once per launch (their ~450
             # re-reads per launch are served by L2 / Infinity Cache and are priced on the LDS-atomic roof instead)
             "k_tail_select": roof("k_tail_select (sparse tail + histogram select)", "hbm", tm["select_ms"],
@@ -259,7 +260,8 @@ def main():
                                   "12 * k B per prediction (SURVEY 8d)", launches=steps, key="k_predict_knn"),
         }
         g = kernels["k_gemm_nt_bf16"]
-        g["executed_tflops"] = (tm["gemm_flops_executed"] / launches) / (tm["gemm_ms"] / launches / 1e3) / 1e12 if tm["gemm_ms"] > 0 else 0.0
+        g["executed_tflops"] = tm["gemm_flops_executed"] / (tm["gemm_ms"] / 1e3) / 1e12 if tm["gemm_ms"] > 0 else 0.0
+        g["symmetric"] = tm["gemm_launches"] < tm["select_launches"]  # one launch computes the tiles on/above the diagonal and mirrors them
         g["executed_frac"] = g["executed_tflops"] / MFMA_BF16_DENSE_PEAK_TFLOPS
         # the tail's other roof: integer LDS atomics (one per tail pair product)
         ts = kernels["k_tail_select"]

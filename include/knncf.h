@@ -103,6 +103,7 @@ typedef struct knncf_timings {
     double tail_pair_updates;      /* sum over tail items of (raters in panel) x (raters) */
     double rerank_row_bytes;       /* K6b algorithmic traffic: 12 B x ratings of every re-ranked candidate */
     double select_row_bytes;       /* K6 algorithmic traffic: panel entry size x (rows x users) similarity panel entries read */
+    int64_t select_launches;       /* row-block launches of select / re-rank (the symmetric GEMM is ONE launch for all of them) */
 } knncf_timings;
 
 const char* knncf_version(void);

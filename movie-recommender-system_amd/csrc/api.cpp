@@ -53,6 +53,9 @@ struct knncf_handle {
     hipStream_t stream2 = nullptr;
     DArr<bf16_t> Apanel[2];
     DArr<float> S[2];
+    DArr<float> S_full;            // symmetric path: the whole U_pad x U_pad similarity panel (raw storage)
+    DArr<uint32_t> sym_tiles;      // its tile order (gemm_sym_tile_list), cached per U_pad
+    int32_t sym_tiles_n = 0;       // tiles per side the cached list was built for
     hipEvent_t ev_produced[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr}, ev_ready = nullptr;
     int32_t* pinned_cnt = nullptr;
     size_t pinned_cap = 0;
@@ -67,6 +70,7 @@ struct knncf_handle {
     // test scratch
     DArr<int32_t> t_du, t_di, t_users, t_items;
     DArr<double> t_pred, t_err, t_ratings, t_partial, scalar_out;
+    DArr<unsigned long long> scalar_u64;
     DArr<uint8_t> t_owned;
     DArr<int64_t> t_counts;
     // host mirrors for scalar queries
@@ -307,15 +311,46 @@ void build_neighbors(knncf_handle* h, int32_t count) {
     const int64_t K_pad = h->K_pad;
     const int32_t head = h->head;
     h->tm.head_items = head;
+    const int64_t s_elem = s_fp16 ? 2 : 4;
+    // SYMMETRIC PATH (whole-matrix builds on one GPU): S = B B^T is symmetric, so when (nearly) every user's row is wanted
+    // the whole U_pad x U_pad panel is produced by ONE launch that computes the tiles on and above the diagonal and stores
+    // each of them twice (gemm.hip: SYM) — half the MFMA work of the row-block launches, the same stored values bit for
+    // bit — and the row blocks below only run select + re-rank, reading their rows out of it by dense user index.
+    // 288 GB of HBM hold it easily at the ml-25m shape (53 GB as fp16); shapes whose square does not fit (syn-1M: 2 TB)
+    // and partial / sharded builds take the row-block path.
+    const size_t sym_bytes = (size_t)U_pad * (size_t)U_pad * (size_t)s_elem;
+    const bool use_sym = h->cfg.shard_count == 1 && (int64_t)count * 2 >= tr.U && U_pad / 256 < 65536 &&
+                         sym_bytes <= (free_b + h->S_full.bytes()) / 3 && !getenv("KNNCF_DEBUG_NO_SYMMETRIC_GEMM");
+    if (use_sym) {
+        h->S_full.ensure((sym_bytes + 3) / 4);
+        const int32_t n_tiles = (int32_t)(U_pad / 256);
+        if (h->sym_tiles_n != n_tiles) {
+            std::vector<uint32_t> list;
+            gemm_sym_tile_list(n_tiles, list);
+            h->sym_tiles.ensure(list.size());
+            KN_HIP(hipMemcpyAsync(h->sym_tiles.p, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            KN_HIP(hipStreamSynchronize(st));
+            h->sym_tiles_n = n_tiles;
+        }
+        const int64_t n_listed = (int64_t)n_tiles * (n_tiles + 1) / 2;
+        Stage s(h, &h->tm.gemm_ms);
+        launch_gemm_sym(h->Bpanel.p, h->S_full.p, s_fp16, U_pad, h->K_pad, h->K_pad, U_pad, fp16, h->sym_tiles.p, n_listed, st);
+        h->tm.gemm_launches += 1;
+        h->tm.gemm_flops_executed += 2.0 * 65536.0 * (double)n_listed * (double)h->K_pad;
+        // ordered pairs (row, other user) of the rows actually wanted x the dense columns (bench.py halves it)
+        h->tm.gemm_flops_algorithmic += 2.0 * (double)count * (double)(tr.U - 1) * (double)h->head;
+        KN_HIP(hipMemGetInfo(&free_b, &total_b));
+    } else {
+        h->S_full.release();
+    }
     // rows per block from the similarity-panel budget (two slots: the producer stream runs ahead)
     size_t held = 0;
     for (int s = 0; s < 2; ++s) held += h->S[s].bytes() + h->Apanel[s].bytes();
     held += h->sel.cand_idx.bytes() + h->sel.cand_approx.bytes() + h->sel.grp_v0.bytes() + h->sel.grp_x.bytes();
     int64_t budget = h->cfg.workspace_bytes > 0 ? h->cfg.workspace_bytes / 2
                                                 : (int64_t)std::min<size_t>((size_t)48 << 30, (free_b + held) / 4);
-    const int64_t s_elem = s_fp16 ? 2 : 4;
     // per panel row: the similarity row, the operand row, the shortlist store and the provisional group store
-    int64_t per_row = U_pad * s_elem + K_pad * 2 + (int64_t)shortlist_cap(nt.k, tr.U) * 8 + (int64_t)select_gcap(nt.k) * 36;
+    int64_t per_row = (use_sym ? 0 : U_pad * s_elem + K_pad * 2) + (int64_t)shortlist_cap(nt.k, tr.U) * 8 + (int64_t)select_gcap(nt.k) * 36;
     int64_t R = std::max<int64_t>(256, (budget / per_row) / 256 * 256);
     R = std::min<int64_t>(R, round_up(count, 256));
     const int64_t n_blocks = ceil_div(count, R);
@@ -323,8 +358,8 @@ void build_neighbors(knncf_handle* h, int32_t count) {
     // KNNCF_FLAG_OVERLAP: run the producer one block ahead.  Measured on MI355X (ml-25m shape): -5 % step
     // time, but GEMM and re-rank then contend for LDS/CUs (GEMM 890 -> 506 TFLOP/s), so it is opt-in.
     const bool overlap = (h->cfg.flags & KNNCF_FLAG_OVERLAP) != 0;
-    const int slots = (overlap && n_blocks > 1) ? 2 : 1;
-    for (int s = 0; s < slots; ++s) {
+    const int slots = (overlap && n_blocks > 1 && !use_sym) ? 2 : 1;
+    for (int s = 0; s < slots && !use_sym; ++s) {
         h->S[s].ensure((size_t)(R * U_pad * s_elem + 3) / 4);  // DArr<float> used as raw storage
         h->Apanel[s].ensure((size_t)R * K_pad);
     }
@@ -363,11 +398,11 @@ void build_neighbors(knncf_handle* h, int32_t count) {
         const int32_t* d_rows = h->build_list.p + rb;
         const int slot = (int)(b % slots);
         if (b >= slots) KN_HIP(hipStreamWaitEvent(sp, h->ev_consumed[slot], 0));  // S[slot] has been read
-        {
+        if (!use_sym) {
             Stage s(h, &h->tm.densify_ms, sp);
             launch_densify(tr, d_rows, 0, rows, h->colmap.p, h->Apanel[slot].p, K_pad, M, fp16, sp);
         }
-        {
+        if (!use_sym) {
             Stage s(h, &h->tm.gemm_ms, sp);
             launch_gemm_nt(h->Apanel[slot].p, h->Bpanel.p, h->S[slot].p, s_fp16, M, U_pad, K_pad, K_pad, K_pad, U_pad, fp16, sp);
             h->tm.gemm_launches += 1;
@@ -381,8 +416,9 @@ void build_neighbors(knncf_handle* h, int32_t count) {
         {
             // sparse tail (LDS atomics per row tile) + histogram select, fused: one pass over S
             Stage s(h, &h->tm.select_ms, sc);
-            launch_tail_select(tr, h->colmap.p, head < tr.I, h->S[slot].p, s_fp16, U_pad, rows, d_rows, nt.k, eps_opnd, eps_rest, cap,
+            launch_tail_select(tr, h->colmap.p, head < tr.I, use_sym ? h->S_full.p : h->S[slot].p, use_sym, s_fp16, U_pad, rows, d_rows, nt.k, eps_opnd, eps_rest, cap,
                                h->sel.cand_idx.p, h->sel.cand_approx.p, h->sel.cand_cnt.p, h->sel.cand_eps.p, h->sel.grp_v0.p, h->sel.grp_x.p, select_gcap(nt.k), sc);
+            h->tm.select_launches += 1;
             h->tm.tail_pair_updates += h->tail_pairs_full * ((double)rows / (double)tr.U);
             h->tm.select_row_bytes += (double)s_elem * (double)rows * (double)tr.U;
         }
@@ -523,15 +559,30 @@ void run_predict(knncf_handle* h, int predictor, const int32_t* d_users, const i
         double* pred = d_pred_out ? d_pred_out : h->t_pred.p;
         const uint32_t* d_order = nullptr;
         const bool by_item = tr.ib_words > 0 && tr.ib_words * 12 <= 48 * 1024;
+        int64_t n_rows = n;  // rows the prediction kernel walks
         if (kind == KNNCF_PRED_KNN) {  // rows sorted by item (the item's rater bitmap lives in LDS) or else by user
             PrepScratch& sc = h->prep;
             sc.k64_a.ensure(n); sc.k64_b.ensure(n); sc.v32_a.ensure(n); sc.v32_b.ensure(n);
-            launch_user_keys(n, by_item ? h->t_di.p : h->t_du.p, sc.k64_a.p, sc.v32_a.p, st);
-            sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.v32_a.p, sc.v32_b.p, n, 32, st);
+            if (h->cfg.shard_count > 1) {
+                // the test set is replicated on every shard, the work is not: this shard's rows sort first and only they are
+                // predicted; the other rows' error / ownership cells are cleared here instead of by the kernel
+                h->scalar_u64.ensure(1);
+                KN_HIP(hipMemsetAsync(h->scalar_u64.p, 0, sizeof(unsigned long long), st));
+                KN_HIP(hipMemsetAsync(h->t_err.p, 0, (size_t)n * sizeof(double), st));
+                KN_HIP(hipMemsetAsync(h->t_owned.p, 0, (size_t)n, st));
+                launch_owned_keys(n, by_item ? h->t_di.p : h->t_du.p, h->t_du.p, tr.own_lo, tr.own_hi, h->cfg.shard_rank == 0,
+                                  sc.k64_a.p, sc.v32_a.p, h->scalar_u64.p, st);
+                sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.v32_a.p, sc.v32_b.p, n, 33, st);
+                n_rows = (int64_t)fetch(h, h->scalar_u64.p, 0);
+            } else {
+                launch_user_keys(n, by_item ? h->t_di.p : h->t_du.p, sc.k64_a.p, sc.v32_a.p, st);
+                sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.v32_a.p, sc.v32_b.p, n, 32, st);
+            }
             d_order = sc.v32_b.p;
         }
-        launch_predict(tr, table, kind, n, h->t_du.p, h->t_di.p, d_ratings, d_order, by_item, pred, h->t_err.p, h->t_owned.p,
-                       h->cfg.shard_rank == 0, st);
+        if (n_rows > 0)
+            launch_predict(tr, table, kind, n_rows, h->t_du.p, h->t_di.p, d_ratings, d_order, by_item, pred, h->t_err.p, h->t_owned.p,
+                           h->cfg.shard_rank == 0, st);
         if (sum_abs_err || count) {
             const int32_t nb = 1024;
             launch_reduce_err(h->t_err.p, h->t_owned.p, n, h->t_partial.p, h->t_counts.p, nb, st);

@@ -116,6 +116,12 @@ void launch_colmap(const Train& tr, int32_t H, int32_t* d_colmap, hipStream_t st
 void launch_gemm_nt(const bf16_t* A, const bf16_t* B, void* C, bool c_fp16, int64_t M, int64_t N, int64_t K,
                     int64_t lda, int64_t ldb, int64_t ldc, bool fp16, hipStream_t st);
 
+// the whole symmetric matrix at once: C[N][ldc] = B B^T computed on and above the diagonal (256 x 256 tiles in the order of
+// the tile list) and mirrored below it; the stored values are bit for bit those of launch_gemm_nt(B, B, ...)
+void gemm_sym_tile_list(int32_t n_tiles, std::vector<uint32_t>& out);
+void launch_gemm_sym(const bf16_t* B, void* C, bool c_fp16, int64_t N, int64_t K, int64_t ldb, int64_t ldc, bool fp16,
+                     const uint32_t* d_tile_list, int64_t n_listed, hipStream_t st);
+
 // ---- select.hip: K6 + K6b --------------------------------------------------------------
 struct NeighborTable {
     int32_t k = 0;     // requested k
@@ -144,7 +150,8 @@ struct SelectScratch {
 
 // per panel row: S[r][:] += sparse tail (items with colmap < 0), then threshold + shortlist:
 // candidates v with S[r][v] >= T_r - 2 eps_r; eps_r = eps_opnd * ||head part of row r|| + eps_rest + per-row terms
-void launch_tail_select(const Train& tr, const int32_t* d_colmap, bool has_tail, const void* S, bool s_fp16, int64_t lds,
+// s_by_user: S is the whole matrix and row r's similarities are S[d_row_user[r]] (symmetric path); else S[r]
+void launch_tail_select(const Train& tr, const int32_t* d_colmap, bool has_tail, const void* S, bool s_by_user, bool s_fp16, int64_t lds,
                         int32_t n_rows, const int32_t* d_row_user, int32_t k, float eps_opnd, float eps_rest, int32_t cap,
                         int32_t* cand_idx, float* cand_approx, int32_t* cand_cnt, float* cand_eps, int32_t* grp_v0, float* grp_x,
                         int32_t gcap, hipStream_t st);
@@ -171,6 +178,10 @@ void launch_predict(const Train& tr, const NeighborTable* nt, int predictor, int
                     bool unknown_users_owned, hipStream_t st);
 // (key, value) = (dense user or 2^32-1, row) of every test row: sorted, it is the d_order of the grouped kNN kernel
 void launch_user_keys(int64_t n, const int32_t* d_du, uint64_t* d_key, uint32_t* d_val, hipStream_t st);
+// sharded handles: key = d_src (dense user or item) for the rows of this shard's users, 2^32 for everybody else's;
+// *d_n_owned += number of rows of this shard
+void launch_owned_keys(int64_t n, const int32_t* d_src, const int32_t* d_du, int32_t own_lo, int32_t own_hi, bool unknown_owned,
+                       uint64_t* d_key, uint32_t* d_val, unsigned long long* d_n_owned, hipStream_t st);
 // deterministic fixed-shape reduction: sum of d_abs_err and count of d_owned
 void launch_reduce_err(const double* d_abs_err, const uint8_t* d_owned, int64_t n, double* d_partials,
                        int64_t* d_counts, int32_t n_blocks, hipStream_t st);

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "engine.h"
 
@@ -118,7 +119,13 @@ struct EpiGeom {
     static constexpr int PASS_ROWS = IPP * 32;
     static constexpr int PASSES = WAVES_M * (WM / IPP);
     static constexpr int RS = TB * ESZ + 16;                             // LDS row stride of the image
-    static constexpr int IMAGE = PASS_ROWS * RS;
+    static constexpr int IMAGE_N = PASS_ROWS * RS;
+    // symmetric launches also write the tile's mirror image: the pass's PASS_ROWS rows become PASS_ROWS columns of all TB
+    // rows of the transposed tile.  Row stride 272 B for both element sizes: the two 32-lane halves of a wave (columns c
+    // and c + 4 of the tile = rows 4 apart of this image) then sit 16 banks apart.
+    static constexpr int RS_T = PASS_ROWS * ESZ + 16;
+    static constexpr int IMAGE_T = TB * RS_T;
+    static constexpr int IMAGE = IMAGE_N > IMAGE_T ? IMAGE_N : IMAGE_T;
     static constexpr int STAGE = TileGeom<TB>::STAGE_BYTES;
     static constexpr int PAD = IMAGE > STAGE ? ((IMAGE - STAGE + 1023) / 1024) * 1024 : 0;
     static constexpr int SMEM = 2 * STAGE + 2 * PAD;
@@ -130,10 +137,14 @@ struct EpiGeom {
 // the stores / the MFMAs ablated: the per-tile kernel spent 10 of its 23 ms waiting for its own stores at K = 256).
 // (Splitting the waves into loaders and storers, so that no counted load wait stands behind a store, was slower:
 // 9.6 vs 6.9 ms per launch — four waves do not issue the LDS-DMA stream fast enough.)
-template <bool F16, class OT, int WM, int WN, int WAVES_M, int WAVES_N>
+// SYM (A == B, C square): only the tiles on and above the diagonal are computed, in the order of `tile_list` (tile row in
+// the low 16 bits, tile column in the high 16); every off-diagonal tile is stored twice, as it is and mirrored — S is
+// symmetric and its mirror is the same sum of the same products in the same order, so the stored values are bit for bit
+// what the full-square launch stores, for half the MFMA work.
+template <bool F16, class OT, int WM, int WN, int WAVES_M, int WAVES_N, bool SYM>
 __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64)
 k_gemm_nt_bf16(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, OT* __restrict__ C, int tiles_m,
-               int tiles_n, int k_tiles, int64_t lda, int64_t ldb, int64_t ldc) {
+               int tiles_n, int k_tiles, int64_t lda, int64_t ldb, int64_t ldc, const uint32_t* __restrict__ tile_list, int n_listed) {
     constexpr int WAVES = WAVES_M * WAVES_N;
     constexpr int TBM = WAVES_M * WM * 32, TBN = WAVES_N * WN * 32;
     static_assert(TBM == TBN, "square block tiles: both operand tiles share one staging routine");
@@ -146,7 +157,7 @@ k_gemm_nt_bf16(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, OT* _
     // XCD-aware tile order: blocks that share an XCD (equal blockIdx % 8, observed round-robin placement; speed
     // only) own one contiguous range of the tile sequence and walk it side by side, so that A/B panels are reused
     // out of that XCD's L2.  Every tile is visited exactly once for any grid size.
-    const int nwg = tiles_m * tiles_n;
+    const int nwg = SYM ? n_listed : tiles_m * tiles_n;
     const int xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
     const int xcd_first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     const int xcd_end = xcd_first + (xcd < r ? q + 1 : q);
@@ -162,6 +173,12 @@ k_gemm_nt_bf16(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, OT* _
 
     // grouped ordering: 8 tile-rows at a time, column-major inside a group
     auto tile_of = [&](int wg, int& tm, int& tn) {
+        if (SYM) {
+            const uint32_t packed = tile_list[wg];
+            tm = (int)(packed & 0xffffu);
+            tn = (int)(packed >> 16);
+            return;
+        }
         const int GROUP = 8;
         const int group_sz = GROUP * tiles_n;
         const int gid = wg / group_sz;
@@ -291,6 +308,38 @@ k_gemm_nt_bf16(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, OT* _
                     __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(reinterpret_cast<char*>(Cg + (int64_t)row * ldc) + ch * 16));
                 }
                 __syncthreads();  // the image is rewritten by the next pass / restaged by the next tile
+                if (SYM && tm != tn) {
+                    // the mirror image of the same rows: element (row, col) of the tile goes to [col][row - pass rows' first];
+                    // one element per LDS write (a lane holds one row and runs of 4 columns = 4 rows of this image), then the
+                    // same 16-byte copy-out, into the tile (tn, tm) of C
+                    constexpr int RS_T = EG::RS_T;
+                    constexpr int CHT = PASS_ROWS * ESZ / 16;                  // 16-byte pieces per row of the mirror image
+                    if (wr == wrp) {
+#pragma unroll
+                        for (int ii = 0; ii < IPP; ++ii)
+#pragma unroll
+                            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        const int i = i0 + ii;
+                                        const int col = wc * (WN * 32) + j * 32 + 8 * g + 4 * fhalf + e;
+                                        OT* dst = reinterpret_cast<OT*>(img + col * RS_T) + (ii * 32 + frow);
+                                        if (ESZ == 2) *dst = (OT)fminf(fmaxf(acc[i][j][4 * g + e], -1.0f), 1.0f);
+                                        else *dst = (OT)acc[i][j][4 * g + e];
+                                    }
+                    }
+                    __syncthreads();
+                    OT* Ct = C + (int64_t)tn * TBN * ldc + (int64_t)tm * TBM + wrp * (WM * 32) + i0 * 32;
+                    for (int idx = threadIdx.x; idx < TBN * CHT; idx += WAVES * 64) {
+                        const int row = idx / CHT, ch = idx - row * CHT;
+                        const uint4 v = *reinterpret_cast<const uint4*>(img + row * RS_T + ch * 16);
+                        typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+                        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(reinterpret_cast<char*>(Ct + (int64_t)row * ldc) + ch * 16));
+                    }
+                    __syncthreads();
+                }
             }
         }
         if (!more) break;
@@ -302,29 +351,29 @@ k_gemm_nt_bf16(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, OT* _
     }
 }
 
-template <bool F16, class OT, int WM, int WN, int WAVES_M, int WAVES_N>
+template <bool F16, class OT, int WM, int WN, int WAVES_M, int WAVES_N, bool SYM>
 static void launch_gemm_cfg(const bf16_t* A, const bf16_t* B, OT* C, int64_t M, int64_t N, int64_t K, int64_t lda,
-                            int64_t ldb, int64_t ldc, hipStream_t st) {
+                            int64_t ldb, int64_t ldc, const uint32_t* tile_list, int64_t n_listed, hipStream_t st) {
     constexpr int TB = WAVES_M * WM * 32;
     constexpr int SMEM = EpiGeom<OT, WM, WAVES_M, TB>::SMEM;
     static_assert(SMEM <= 160 * 1024, "gemm: LDS plan exceeds the CU's 160 KiB");
-    const int64_t tiles = (M / TB) * (N / TB);
+    const int64_t tiles = SYM ? n_listed : (M / TB) * (N / TB);
     KN_REQUIRE(tiles > 0 && tiles < (1ll << 31), KNNCF_E_INVALID, "gemm: grid too large");
     // resident workgroups of this kernel on the CURRENT device (dynamic-LDS attribute, CU count, occupancy): per device
     static PerDeviceState state;
     const int64_t slots = (int64_t)per_device_at_least(state, 1, [&](size_t) {
-        KN_HIP(hipFuncSetAttribute((const void*)k_gemm_nt_bf16<F16, OT, WM, WN, WAVES_M, WAVES_N>,
+        KN_HIP(hipFuncSetAttribute((const void*)k_gemm_nt_bf16<F16, OT, WM, WN, WAVES_M, WAVES_N, SYM>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         int dev = 0, cus = 0, per_cu = 0;
         KN_HIP(hipGetDevice(&dev));
         KN_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        KN_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gemm_nt_bf16<F16, OT, WM, WN, WAVES_M, WAVES_N>,
+        KN_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gemm_nt_bf16<F16, OT, WM, WN, WAVES_M, WAVES_N, SYM>,
                                                             WAVES_M * WAVES_N * 64, SMEM));
         return (size_t)std::max(1, cus * (per_cu > 0 ? per_cu : 1));
     });
     const unsigned grid = (unsigned)(tiles < slots ? tiles : slots);
-    k_gemm_nt_bf16<F16, OT, WM, WN, WAVES_M, WAVES_N><<<grid, WAVES_M * WAVES_N * 64, SMEM, st>>>(
-        A, B, C, (int)(M / TB), (int)(N / TB), (int)(K / BK), lda, ldb, ldc);
+    k_gemm_nt_bf16<F16, OT, WM, WN, WAVES_M, WAVES_N, SYM><<<grid, WAVES_M * WAVES_N * 64, SMEM, st>>>(
+        A, B, C, (int)(M / TB), (int)(N / TB), (int)(K / BK), lda, ldb, ldc, tile_list, (int)n_listed);
     KN_HIP(hipGetLastError());
 }
 
@@ -335,8 +384,8 @@ static void launch_gemm_t(const bf16_t* A, const bf16_t* B, OT* C, int64_t M, in
     // less LDS read traffic per flop — measured the same: 30.6 vs 30.7 ms at K = 448, 52.8 vs 51.9 ms at K = 1024)
     static const bool force_small = getenv("KNNCF_GEMM_TILE128") != nullptr;  // A/B switch for measurements
     // (16 waves on the 256 x 256 tile, each a 64 x 64 sub-tile, 4 waves per SIMD: 8.3 vs 6.9 ms per launch at K = 256)
-    if (M % 256 == 0 && N % 256 == 0 && !force_small) launch_gemm_cfg<F16, OT, 4, 2, 2, 4>(A, B, C, M, N, K, lda, ldb, ldc, st);
-    else launch_gemm_cfg<F16, OT, 2, 2, 2, 2>(A, B, C, M, N, K, lda, ldb, ldc, st);
+    if (M % 256 == 0 && N % 256 == 0 && !force_small) launch_gemm_cfg<F16, OT, 4, 2, 2, 4, false>(A, B, C, M, N, K, lda, ldb, ldc, nullptr, 0, st);
+    else launch_gemm_cfg<F16, OT, 2, 2, 2, 2, false>(A, B, C, M, N, K, lda, ldb, ldc, nullptr, 0, st);
 }
 
 // C is fp16 (c_fp16) or fp32; operands fp16 (fp16) or bf16.  M, N multiples of 128 (256 selects the large tile)
@@ -348,6 +397,27 @@ void launch_gemm_nt(const bf16_t* A, const bf16_t* B, void* C, bool c_fp16, int6
     else if (fp16) launch_gemm_t<true, float>(A, B, static_cast<float*>(C), M, N, K, lda, ldb, ldc, st);
     else if (c_fp16) launch_gemm_t<false, _Float16>(A, B, static_cast<_Float16*>(C), M, N, K, lda, ldb, ldc, st);
     else launch_gemm_t<false, float>(A, B, static_cast<float*>(C), M, N, K, lda, ldb, ldc, st);
+}
+
+// the 256 x 256 tiles on and above the diagonal of an n_tiles x n_tiles grid, 8 tile rows at a time and column by
+// column inside such a group (the group's operand rows stay in the L2 while its columns stream): tile row | column << 16
+void gemm_sym_tile_list(int32_t n_tiles, std::vector<uint32_t>& out) {
+    out.clear();
+    out.reserve((size_t)n_tiles * (n_tiles + 1) / 2);
+    for (int32_t g = 0; g < n_tiles; g += 8)
+        for (int32_t tn = g; tn < n_tiles; ++tn)
+            for (int32_t tm = g; tm < std::min(g + 8, n_tiles) && tm <= tn; ++tm) out.push_back((uint32_t)tm | ((uint32_t)tn << 16));
+}
+
+// S[N x N] = B B^T for all N rows at once, N a multiple of 256, computed on and above the diagonal and mirrored
+// (fp16 panel storage only: the path that holds the whole similarity matrix)
+void launch_gemm_sym(const bf16_t* B, void* C, bool c_fp16, int64_t N, int64_t K, int64_t ldb, int64_t ldc, bool fp16,
+                     const uint32_t* d_tile_list, int64_t n_listed, hipStream_t st) {
+    KN_REQUIRE(N % 256 == 0 && N / 256 < 65536 && K % BK == 0 && K > 0 && ldb % 8 == 0 && ldc % 8 == 0, KNNCF_E_INVALID, "symmetric gemm: shape not tile-aligned");
+    if (fp16 && c_fp16) launch_gemm_cfg<true, _Float16, 4, 2, 2, 4, true>(B, B, static_cast<_Float16*>(C), N, N, K, ldb, ldb, ldc, d_tile_list, n_listed, st);
+    else if (fp16) launch_gemm_cfg<true, float, 4, 2, 2, 4, true>(B, B, static_cast<float*>(C), N, N, K, ldb, ldb, ldc, d_tile_list, n_listed, st);
+    else if (c_fp16) launch_gemm_cfg<false, _Float16, 4, 2, 2, 4, true>(B, B, static_cast<_Float16*>(C), N, N, K, ldb, ldb, ldc, d_tile_list, n_listed, st);
+    else launch_gemm_cfg<false, float, 4, 2, 2, 4, true>(B, B, static_cast<float*>(C), N, N, K, ldb, ldb, ldc, d_tile_list, n_listed, st);
 }
 
 }  // namespace knncf

@@ -161,7 +161,7 @@ struct Raw8<_Float16> {
 };
 
 template <class ST>
-__global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ S, int64_t ld, int32_t n_rows,
+__global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ S, int32_t s_by_user, int64_t ld, int32_t n_rows,
                                                      const int32_t* __restrict__ row_user, TailArgs T, int32_t U,
                                                      int32_t kk, float eps_opnd, float eps_rest, int32_t cap, int32_t* __restrict__ cand_idx,
                                                      float* __restrict__ cand_approx, int32_t* __restrict__ cand_cnt,
@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
     const int32_t u = row_user[r];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t ub = T.u_ptr[u], ue = T.u_ptr[u + 1];
-    const ST* row = S + (int64_t)r * ld;
+    const ST* row = S + (int64_t)(s_by_user ? u : r) * ld;  // (symmetric path: S is the whole matrix, indexed by dense user)
     int32_t* out_idx = cand_idx + (int64_t)r * cap;
     float* out_apx = cand_approx + (int64_t)r * cap;
     // provisional store of the row: whole GROUPS of 8 columns (first column + the 8 values) whose maximum reached the
@@ -756,13 +756,13 @@ void select_profile_dump() {
 #endif
 
 template <class ST>
-static void launch_tail_select_t(const TailArgs& T, const ST* S, int64_t lds, int32_t n_rows, const int32_t* d_row_user,
+static void launch_tail_select_t(const TailArgs& T, const ST* S, bool s_by_user, int64_t lds, int32_t n_rows, const int32_t* d_row_user,
                                  int32_t U, int32_t kk, float eps_opnd, float eps_rest, int32_t cap, int32_t* cand_idx, float* cand_approx,
                                  int32_t* cand_cnt, float* cand_eps, int32_t* grp_v0, float* grp_x, int32_t gcap, hipStream_t st) {
     const size_t smem = (size_t)TCOLS * 4 + (size_t)NBINS * 4 + (size_t)EMAX * 4 + 2 * ((size_t)EMAX * 12 + (size_t)PMAX * 2) + (2 * (TPB / 64) + 4 + 64) * 4;  // + 64 scratch cells
     static PerDeviceState lds_state;
     ensure_dynamic_lds(lds_state, (const void*)k_tail_select<ST>, smem);
-    k_tail_select<ST><<<n_rows, TPB, smem, st>>>(S, lds, n_rows, d_row_user, T, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap);
+    k_tail_select<ST><<<n_rows, TPB, smem, st>>>(S, s_by_user ? 1 : 0, lds, n_rows, d_row_user, T, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap);
     KN_HIP(hipGetLastError());
 #ifdef KNNCF_SELECT_PROFILE
     KN_HIP(hipStreamSynchronize(st));
@@ -770,7 +770,7 @@ static void launch_tail_select_t(const TailArgs& T, const ST* S, int64_t lds, in
 #endif
 }
 
-void launch_tail_select(const Train& tr, const int32_t* d_colmap, bool has_tail, const void* S, bool s_fp16, int64_t lds,
+void launch_tail_select(const Train& tr, const int32_t* d_colmap, bool has_tail, const void* S, bool s_by_user, bool s_fp16, int64_t lds,
                         int32_t n_rows, const int32_t* d_row_user, int32_t k, float eps_opnd, float eps_rest, int32_t cap,
                         int32_t* cand_idx, float* cand_approx, int32_t* cand_cnt, float* cand_eps, int32_t* grp_v0, float* grp_x,
                         int32_t gcap, hipStream_t st) {
@@ -785,8 +785,8 @@ void launch_tail_select(const Train& tr, const int32_t* d_colmap, bool has_tail,
     static const bool skip_tail = getenv("KNNCF_DEBUG_SKIP_TAIL") != nullptr;
     if (skip_tail) has_tail = false;
     TailArgs T{tr.u_ptr.p, tr.s_col.p, tr.s_pre.p, d_colmap, tr.i_ptr.p, tr.it_pack.p, (uint32_t)(tr.n * 4), tr.it_tile.p, tr.tile_stride, has_tail ? 1 : 0};
-    if (s_fp16) launch_tail_select_t(T, static_cast<const _Float16*>(S), lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, st);
-    else launch_tail_select_t(T, static_cast<const float*>(S), lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, st);
+    if (s_fp16) launch_tail_select_t(T, static_cast<const _Float16*>(S), s_by_user, lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, st);
+    else launch_tail_select_t(T, static_cast<const float*>(S), s_by_user, lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, st);
 }
 
 }  // namespace knncf

@@ -90,7 +90,7 @@ class Timings(C.Structure):
                 ("gemm_flops_algorithmic", C.c_double), ("shortlist_total", C.c_int64),
                 ("fallback_rows", C.c_int64), ("max_bound_violation", C.c_double),
                 ("head_items", C.c_int64), ("tail_pair_updates", C.c_double),
-                ("rerank_row_bytes", C.c_double), ("select_row_bytes", C.c_double)]
+                ("rerank_row_bytes", C.c_double), ("select_row_bytes", C.c_double), ("select_launches", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
