@@ -240,7 +240,7 @@ int32_t shortlist_cap(int32_t k, int32_t U) {
 // Width H of the dense head of the hybrid similarity.  Cost model (measured rates, MI355X): a dense
 // column costs 2 * rows * U flops on the MFMA GEMM; a tail item with c raters costs c^2 * rows / U
 // LDS accumulator updates in k_tail_select.  Items are in descending popularity, so the optimum is a prefix.
-int32_t choose_head(knncf_handle* h, int32_t rows_total) {
+int32_t choose_head(knncf_handle* h, int32_t rows_total, bool symmetric) {
     Train& tr = h->tr;
     const int32_t I = tr.I;
     const std::vector<int64_t>& c = tr.pop_count;
@@ -252,8 +252,11 @@ int32_t choose_head(knncf_handle* h, int32_t rows_total) {
     } else if (h->cfg.head_items > 0) {
         H = (int32_t)std::min<int64_t>(h->cfg.head_items, I);
     } else {
-        const double RATE_DENSE = 9.5e14;   // marginal flop/s of k_gemm_nt_bf16 per extra dense column (measured)
-        const double RATE_SPARSE = 1.8e12;  // marginal tail pair products per second through LDS atomics (k_tail_select, measured)
+        // marginal rates measured on MI355X at the ml-25m shape (head sweeps 192 .. 1024, profiles/README.md): full-square
+        // flops per second bought by one more dense column — the symmetric launch computes half of them — and tail pair
+        // products per second through k_tail_select
+        const double RATE_DENSE = symmetric ? 2.8e15 : 1.2e15;
+        const double RATE_SPARSE = 2.3e12;
         const double frac = (double)rows_total / (double)tr.U;
         const double U_pad = (double)round_up(tr.U, 256);
         double best = 1e300;
@@ -293,9 +296,19 @@ void build_neighbors(knncf_handle* h, int32_t count) {
     const int64_t U_pad = h->U_pad;
     size_t free_b = 0, total_b = 0;
     KN_HIP(hipMemGetInfo(&free_b, &total_b));
+    const int64_t s_elem = s_fp16 ? 2 : 4;
+    // SYMMETRIC PATH (whole-matrix builds on one GPU): S = B B^T is symmetric, so when (nearly) every user's row is wanted
+    // the whole U_pad x U_pad panel is produced by ONE launch that computes the tiles on and above the diagonal and stores
+    // each of them twice (gemm.hip: SYM) — half the MFMA work of the row-block launches, the same stored values bit for
+    // bit — and the row blocks below only run select + re-rank, reading their rows out of it by dense user index.
+    // 288 GB of HBM hold it easily at the ml-25m shape (53 GB as fp16); shapes whose square does not fit (syn-1M: 2 TB)
+    // and partial / sharded builds take the row-block path.
+    const size_t sym_bytes = (size_t)U_pad * (size_t)U_pad * (size_t)s_elem;
+    const bool use_sym = h->cfg.shard_count == 1 && (int64_t)count * 2 >= tr.U && U_pad / 256 < 65536 &&
+                         sym_bytes <= (free_b + h->S_full.bytes()) / 3 && !getenv("KNNCF_DEBUG_NO_SYMMETRIC_GEMM");
     if (!h->b_ready) {
         // hybrid similarity: the H most-rated items are dense MFMA columns, the rest a sparse tail
-        h->head = choose_head(h, count);
+        h->head = choose_head(h, count, use_sym);
         h->K_pad = round_up(h->head, 64);
         size_t need = (size_t)U_pad * h->K_pad * sizeof(bf16_t);
         KN_REQUIRE(need < free_b + h->Bpanel.bytes(), KNNCF_E_UNSUPPORTED,
@@ -311,16 +324,6 @@ void build_neighbors(knncf_handle* h, int32_t count) {
     const int64_t K_pad = h->K_pad;
     const int32_t head = h->head;
     h->tm.head_items = head;
-    const int64_t s_elem = s_fp16 ? 2 : 4;
-    // SYMMETRIC PATH (whole-matrix builds on one GPU): S = B B^T is symmetric, so when (nearly) every user's row is wanted
-    // the whole U_pad x U_pad panel is produced by ONE launch that computes the tiles on and above the diagonal and stores
-    // each of them twice (gemm.hip: SYM) — half the MFMA work of the row-block launches, the same stored values bit for
-    // bit — and the row blocks below only run select + re-rank, reading their rows out of it by dense user index.
-    // 288 GB of HBM hold it easily at the ml-25m shape (53 GB as fp16); shapes whose square does not fit (syn-1M: 2 TB)
-    // and partial / sharded builds take the row-block path.
-    const size_t sym_bytes = (size_t)U_pad * (size_t)U_pad * (size_t)s_elem;
-    const bool use_sym = h->cfg.shard_count == 1 && (int64_t)count * 2 >= tr.U && U_pad / 256 < 65536 &&
-                         sym_bytes <= (free_b + h->S_full.bytes()) / 3 && !getenv("KNNCF_DEBUG_NO_SYMMETRIC_GEMM");
     if (use_sym) {
         h->S_full.ensure((sym_bytes + 3) / 4);
         const int32_t n_tiles = (int32_t)(U_pad / 256);

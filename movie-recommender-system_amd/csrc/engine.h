@@ -78,7 +78,7 @@ struct Train {
 };
 
 // status word bits written by kernels
-enum : uint32_t { ST_NONFINITE = 1u, ST_DUPLICATE = 2u, ST_NOT_DYADIC = 4u };
+enum : uint32_t { ST_NONFINITE = 1u, ST_DUPLICATE = 2u, ST_NOT_DYADIC = 4u, ST_SMALL_ROW = 8u };
 
 struct PrepScratch {
     SortWorkspace sort;

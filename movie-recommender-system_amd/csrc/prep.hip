@@ -113,6 +113,13 @@ __global__ void k_segment_ptr_u32(int64_t n, const uint32_t* __restrict__ sorted
     ptr[s] = lo;
 }
 
+// a user with <= 4 ratings: its item set is a Set1..Set4 (insertion order), and which order a pair's similarity is summed in
+// then depends on the closures' evaluation history
+__global__ void k_flag_small_rows(int32_t U, const int64_t* __restrict__ u_ptr, uint32_t* __restrict__ status) {
+    const int32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u < U && u_ptr[u + 1] - u_ptr[u] <= 4) atomicOr(status, (uint32_t)ST_SMALL_ROW);
+}
+
 __global__ void k_iota(int64_t n, uint32_t* __restrict__ v) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n) v[t] = (uint32_t)t;
@@ -425,9 +432,15 @@ void prep_fit(Train& tr, PrepScratch& sc, int32_t shard_rank, int32_t shard_coun
 
     // K1: average :94 — left fold over the file; exact in any order for dyadic ratings
     k_check_dyadic<<<nblocks(n), TPB, 0, st>>>(n, tr.rating.p, sc.status.p);
+    if (shard_count > 1) k_flag_small_rows<<<nblocks(tr.U), TPB, 0, st>>>(tr.U, tr.u_ptr.p, sc.status.p);
     KN_HIP(hipGetLastError());
     uint32_t status = read_status(sc, st);
     KN_REQUIRE(!(status & ST_DUPLICATE), KNNCF_E_DUPLICATE, "fit: duplicate (user,item) training rows");
+    // The summation order of a pair with a <= 4-rating user follows the memo history of the reference's closures; a single
+    // handle models it (nbr_seq), but the shards do not exchange their build sequence numbers: refused rather than
+    // answered differently from the single-GPU run.  Every rank holds all rows, so every rank refuses alike.
+    KN_REQUIRE(!(status & ST_SMALL_ROW), KNNCF_E_UNSUPPORTED,
+               "fit: a user with <= 4 ratings in a sharded fit (the result would depend on cross-shard evaluation order, SURVEY N6); fit it on one handle");
     sc.dsum.ensure(2);
     KN_HIP(hipMemsetAsync(sc.dsum.p, 0, 2 * sizeof(double), st));
     if (status & ST_NOT_DYADIC) k_sequential_sum<<<1, TPB, 0, st>>>(n, tr.rating.p, sc.dsum.p);

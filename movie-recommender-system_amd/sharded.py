@@ -89,15 +89,45 @@ def _all_gather_segments(dist, arrays, lo, hi, ranges):
             a[l:h] = recv[base + j * seg: base + j * seg + (h - l)]
 
 
+class ShardFitError(RuntimeError):
+    """Another rank's fit failed; every rank raises so that none blocks in the exchange."""
+
+    def __init__(self, status, message):
+        super().__init__(message)
+        self.status = status
+
+
 class ShardedKnn:
     def __init__(self, engine, dist=None, rank=0, world=1):
         self.engine, self.dist, self.rank, self.world = engine, dist, rank, world
 
     def fit(self, users, items, ratings):
-        self.engine.fit_device(users, items, ratings)
+        """fit + the one exchange + commit.  The fit STATUS is collective: a rank whose part of the fit fails (a
+        non-finite deviation among ITS users, a device error, out of memory) must not leave the others waiting in the
+        all-gather, so every rank first learns whether all of them succeeded and all of them raise otherwise."""
+        err = None
+        try:
+            self.engine.fit_device(users, items, ratings)
+        except Exception as e:  # reported collectively below
+            err = e
         if self.world > 1:
+            self._raise_together(err, users.device)
             self.exchange()
+        elif err is not None:
+            raise err
         self.engine.shard_commit()
+
+    def _raise_together(self, err, device):
+        import torch
+
+        code = 0 if err is None else int(getattr(err, "status", -1)) or -1
+        flag = torch.tensor([code], dtype=torch.int64, device=device)
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)   # status codes are negative: MIN = "the worst"
+        worst = int(flag.item())
+        if err is not None:
+            raise err
+        if worst != 0:
+            raise ShardFitError(worst, f"fit failed on another rank (status {worst}); this rank's part was fine")
 
     def exchange(self):
         import torch

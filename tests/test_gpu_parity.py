@@ -234,10 +234,15 @@ def test_fp32_panel_gives_the_same_neighbours(kn, oracle, syn100k, bf16):
     e.close()
 
 
+@pytest.mark.parametrize("symmetric", [True, False])
 @pytest.mark.parametrize("flags", [0, 2])
-def test_several_row_blocks_and_the_overlap_flag(kn, oracle, syn100k, flags):
+def test_several_row_blocks_and_the_overlap_flag(kn, oracle, syn100k, flags, symmetric, monkeypatch):
     """A small workspace cuts the users into 256-row blocks (4 at ml-100k shape); KNNCF_FLAG_OVERLAP (= 2) then runs
-    the GEMM of block b + 1 on a second stream into a second panel slot while block b is selected and re-ranked."""
+    the GEMM of block b + 1 on a second stream into a second panel slot while block b is selected and re-ranked.
+    Whole-matrix builds take the symmetric GEMM (one launch, tiles on/above the diagonal mirrored) in front of the same
+    row blocks; KNNCF_DEBUG_NO_SYMMETRIC_GEMM forces the row-block GEMMs that sharded and partial builds always use."""
+    if not symmetric:
+        monkeypatch.setenv("KNNCF_DEBUG_NO_SYMMETRIC_GEMM", "1")
     d = syn100k
     tr = (d.train.users, d.train.items, d.train.ratings)
     te = (d.test.users, d.test.items, d.test.ratings)
@@ -248,7 +253,8 @@ def test_several_row_blocks_and_the_overlap_flag(kn, oracle, syn100k, flags):
     np.testing.assert_array_equal(e.predict_batch(kn.PRED_KNN, te[0], te[1]), preds)
     assert abs(e.mae(kn.PRED_KNN, *te) - want) <= MAE_TOL
     t = e.timings()
-    assert t["gemm_launches"] >= 4 and t["max_bound_violation"] <= 0.0
+    assert t["select_launches"] >= 4 and t["max_bound_violation"] <= 0.0
+    assert t["gemm_launches"] == (1 if symmetric else t["select_launches"])
     for u in np.unique(d.train.users)[::29]:
         ids, sims = e.neighbors(int(u))
         oids, osims = p.neighbors(int(u))
@@ -467,6 +473,49 @@ def test_ml25m_shape_eight_shards_on_one_gpu(kn, pkg, full25m):
         json.dump({"workload": "syn-25m k=300, 8 shards rehearsed on one MI355X (one after the other)",
                    "single_engine_stage_ms_with_verify_flag": single, "single_engine_step_ms": sum(single.values()),
                    "shards": report, "projected_step_ms_8gpu_excl_exchange": max(x["step_ms"] for x in report)}, fh, indent=1)
+
+
+def test_sharded_fit_refuses_memo_dependent_inputs(kn):
+    """a <= 4-rating user makes values depend on the order closures were evaluated in; one handle models that
+    history, shards do not exchange it: refused on every shard alike instead of differing from the single-GPU run"""
+    users = [1] * 6 + [2] * 6 + [3] * 2
+    items = list(range(6)) + list(range(6)) + [0, 1]
+    ratings = [1.0, 2, 3, 4, 5, 3, 2, 2, 4, 4, 5, 1, 3, 4]
+    kn.Engine(k=2).fit(users, items, ratings)  # fine on one handle
+    for r in range(2):
+        with pytest.raises(kn.KnncfError) as ex:
+            kn.Engine(k=2, shard_rank=r, shard_count=2).fit(users, items, ratings)
+        assert ex.value.status == kn.E_UNSUPPORTED
+
+
+def test_two_handles_two_threads(kn, oracle, syn100k):
+    """per-device kernel state is shared by every handle of the process (common.h: PerDeviceState): two handles driven
+    from two threads at once must both come out right"""
+    import threading
+
+    d = syn100k
+    tr = (d.train.users, d.train.items, d.train.ratings)
+    te = (d.test.users, d.test.items, d.test.ratings)
+    want = {k: oracle.Model(*tr).pipeline(oracle.SIM_COSINE, k).mae(*te) for k in (10, 60)}
+    got, errs = {}, []
+
+    def run(k):
+        try:
+            e = kn.Engine(k=k)
+            e.fit(*tr)
+            got[k] = e.mae(kn.PRED_KNN, *te)
+            e.close()
+        except Exception as ex:  # surfaced below
+            errs.append(ex)
+
+    threads = [threading.Thread(target=run, args=(k,)) for k in (10, 60)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for k in (10, 60):
+        assert abs(got[k] - want[k]) <= MAE_TOL
 
 
 def test_fit_errors(kn):

@@ -76,6 +76,64 @@ class OracleShardEngine:
         return float(np.abs(tr[own] - preds).sum()), int(own.sum())
 
 
+class PoisonedEngine(OracleShardEngine):
+    """fails on one rank only, the way a scale() == 0 user owned by that rank makes knncf_fit_device fail there"""
+
+    class Boom(RuntimeError):
+        status = -2  # KNNCF_E_NONFINITE
+
+    def __init__(self, oracle, rank, world, k, bad_rank):
+        super().__init__(oracle, rank, world, k)
+        self.bad_rank = bad_rank
+
+    def fit_device(self, users, items, ratings):
+        if self.rank == self.bad_rank:
+            raise PoisonedEngine.Boom("non-finite normalized deviation")
+        super().fit_device(users, items, ratings)
+
+
+def _poisoned_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from oracle import knncf_oracle as O
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    synth = importlib.import_module(PKG + ".synth")
+    sharded = importlib.import_module(PKG + ".sharded")
+    d = synth.syn_scaled(60, 60, 1500, seed=3, half_stars=True)
+    tr = tuple(torch.from_numpy(a) for a in (d.train.users, d.train.items, d.train.ratings))
+    model = sharded.ShardedKnn(PoisonedEngine(O, rank, world, 5, bad_rank=1), dist, rank, world)
+    try:
+        model.fit(*tr)
+        out.put((rank, "no error", 0))
+    except PoisonedEngine.Boom as e:
+        out.put((rank, "own", e.status))
+    except sharded.ShardFitError as e:
+        out.put((rank, "other", e.status))
+    dist.barrier()  # nobody is stuck in the all-gather
+    dist.destroy_process_group()
+
+
+def test_fit_failure_on_one_rank_raises_on_every_rank():
+    import torch.multiprocessing as mp
+
+    world = 3
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_poisoned_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict((r, (kind, st)) for r, kind, st in (out.get(timeout=120) for _ in range(world)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results[1] == ("own", -2)
+    assert results[0] == ("other", -2) and results[2] == ("other", -2)
+
+
 def _worker(rank, world, port, k, out):
     sys.path.insert(0, ROOT)
     import torch
@@ -109,7 +167,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_host_path_matches_single_process(world):
     import torch.multiprocessing as mp
 
