@@ -274,9 +274,11 @@ def main():
             "cache_level_bytes": {"achieved": (tm["select_row_bytes"] + 4.0 * tm["tail_pair_updates"]) / (tm["select_ms"] / 1e3) / 1e12 if tm["select_ms"] > 0 else 0.0,
                                   "unit": "TB/s", "definition": "panel bytes + 4 B per tail pair product (L2 / Infinity-Cache re-reads of the rater lists; NOT HBM bytes)"},
         }
-        ts["binding"] = ("neither roof: the kernel is VALU-issue bound (profiles/*_pmc_traffic_*.json, SQ pass: ~70 % VALU issue "
-                         "utilisation, ~16 VALU instructions per 64-entry tail piece); HBM frac on compulsory bytes and the "
-                         "LDS-atomic frac are both reported")
+        ts["binding"] = ("latency / synchronisation, not a throughput roof: SQ pass of profiles/" + PMC_PROFILE + " — VALU issue ~54 % "
+                         "(0.135 instructions per wave-quad-cycle x 4 waves per SIMD), waves waiting 52 %; timing-only ablations "
+                         "(DESIGN.md section 4): panel scan + thresholds 16.5 ms of the 35.6 ms kernel at H = 256, tail set-up / read-out "
+                         "4.4, tail drain 14.6 (6.2 of it loads + LDS atomics, 8.4 instruction issue at 8 VALU per 64-entry piece). "
+                         "HBM frac on compulsory bytes and the LDS-atomic frac are both reported")
         stage_of = {"k_gemm_nt_bf16": "gemm_ms", "k_tail_select": "select_ms", "k_rerank": "rerank_ms", "k_predict_knn": "predict_ms"}
         dominant = max(stage_of, key=lambda n: tm[stage_of[n]])
         out = {

@@ -629,6 +629,7 @@ static void pm_set(pairmap* pm, uint64_t key, int32_t owner) {
 
 struct orc_pipeline {
     const orc_model* m;
+    int32_t n_users; /* = m->U, kept so that freeing the pipeline never reads the model (which may be gone already) */
     int sim_kind;
     int32_t k;
     pairmap memo;
@@ -655,6 +656,7 @@ orc_pipeline* orc_pipeline_create(const orc_model* m, int sim_kind, int32_t k) {
     orc_pipeline* p = (orc_pipeline*)calloc(1, sizeof(orc_pipeline));
     size_t U = (size_t)(m->U > 0 ? m->U : 1), I = (size_t)(m->I > 0 ? m->I : 1);
     p->m = m;
+    p->n_users = m->U;
     p->sim_kind = sim_kind;
     p->k = k;
     p->nn_built = (uint8_t*)calloc(U, 1);
@@ -675,7 +677,7 @@ orc_pipeline* orc_pipeline_create(const orc_model* m, int sim_kind, int32_t k) {
 
 void orc_pipeline_free(orc_pipeline* p) {
     if (!p) return;
-    for (int32_t u = 0; u < p->m->U; ++u) { free(p->nn_ids[u]); free(p->nn_sims[u]); }
+    for (int32_t u = 0; u < p->n_users; ++u) { free(p->nn_ids[u]); free(p->nn_sims[u]); }
     free(p->memo.keys); free(p->memo.owner);
     free(p->nn_built); free(p->nn_cnt); free(p->nn_ids); free(p->nn_sims);
     free(p->mask_sim); free(p->mask_has); free(p->row_sims); free(p->dense_pre);
