@@ -535,10 +535,37 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
     int tile_no = 0;
     uint32_t next_refresh = (uint32_t)GCAP / 4;  // store level that triggers an extra threshold refresh (block-uniform)
     for (int32_t t0 = 0; t0 < U; t0 += TCOLS, ++tile_no) {
+        // the tile's panel entries (requested one tile ago) are unpacked and the next tile's requested as soon as this
+        // wave's share of the drain is done — before it waits for the other waves at the barrier (the drain ends with
+        // vmcnt(0), so the entries have landed; the requests then have the barrier wait, the set-up and this tile's select
+        // work to arrive behind)
+        float sx[CPT];
+        auto take_panel = [&]() {
+#pragma unroll
+            for (int j = 0; j < NG; ++j) raw[j].unpack(&sx[8 * j]);
+            if (t0 + TCOLS < U) {
+#pragma unroll
+                for (int j = 0; j < NG; ++j) {
+                    const int64_t v0 = (int64_t)t0 + TCOLS + 8 * (threadIdx.x + TPB * j);
+                    if (v0 < ld) raw[j].load(row + v0);
+                    else raw[j].zero();
+                }
+            }
+            if (t0 + TCOLS > U || (u >= t0 && u < t0 + TCOLS)) {  // the user itself and the padding never qualify
+#pragma unroll
+                for (int j = 0; j < NG; ++j) {
+                    const int32_t v0 = t0 + 8 * (threadIdx.x + TPB * j);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (v0 + i >= U || v0 + i == u) sx[8 * j + i] = -INFINITY;
+                }
+            }
+        };
         if (pipelined) {
             use_tables(tile_no & 1);
             drain(false);
             PH(4);  // piece descriptors, loads, LDS atomics (this wave)
+            take_panel();
             const bool more = t0 + TCOLS < U;
             if (more) setup_a(tile_no + 1, (tile_no + 1) & 1);
             __syncthreads();  // the tile's tail is complete — and the next tile's piece counts are visible
@@ -566,28 +593,7 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
                 PH(5);  // wait for the other waves
             }
         }
-        // the tile's panel entries (requested one tile ago) are needed only now; the next tile's are requested here,
-        // so that they arrive behind the select work of this tile and the tail work of the next
-        float sx[CPT];
-#pragma unroll
-        for (int j = 0; j < NG; ++j) raw[j].unpack(&sx[8 * j]);
-        if (t0 + TCOLS < U) {
-#pragma unroll
-            for (int j = 0; j < NG; ++j) {
-                const int64_t v0 = (int64_t)t0 + TCOLS + 8 * (threadIdx.x + TPB * j);
-                if (v0 < ld) raw[j].load(row + v0);
-                else raw[j].zero();
-            }
-        }
-        if (t0 + TCOLS > U || (u >= t0 && u < t0 + TCOLS)) {  // the user itself and the padding never qualify
-#pragma unroll
-            for (int j = 0; j < NG; ++j) {
-                const int32_t v0 = t0 + 8 * (threadIdx.x + TPB * j);
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    if (v0 + i >= U || v0 + i == u) sx[8 * j + i] = -INFINITY;
-            }
-        }
+        if (!pipelined) take_panel();
         PH(1);  // unpack + next tile's requests
         if (any_tail) {
             // read the accumulator out and clear it for the next tile (only this thread touches these cells between
