@@ -53,7 +53,9 @@ extern "C" {
 #define KNNCF_PRED_ITEM_AVG 2     /* computeItemAvg :141 */
 #define KNNCF_PRED_BASELINE 3     /* computePrediction :205-237 */
 #define KNNCF_PRED_BASELINE_RDD 4 /* baselinePredictorSpark :362-391 */
-#define KNNCF_PRED_KNN 5          /* predictor(train, weightedSumDeviation(train, getSimilarity(train, k, sim))) predict/kNN.scala:43-44 */
+#define KNNCF_PRED_KNN 5          /* predictor(train, weightedSumDeviation(train, getSimilarity(train, k, sim))) predict/kNN.scala:43-44;
+                                     sim = the handle's similarity: the adjusted cosine or the Jaccard coefficient (any number of users:
+                                     both go through the MFMA GEMM + sparse tail + exact re-rank); similarityOne: KNNCF_E_UNSUPPORTED */
 #define KNNCF_PRED_PERSONALIZED 6 /* predictor(train, weightedSumDeviation(train, sim)) predict/Personalized.scala:61-72, sim = the
                                      handle's similarity itself, no neighbourhood cut.  Cosine / Jaccard keep U x U values: U <= 2048;
                                      cosine additionally needs > 4 ratings per user, else KNNCF_E_UNSUPPORTED */

@@ -48,6 +48,10 @@ struct knncf_handle {
     int32_t head = 0;  // dense head width of the hybrid similarity
     double tail_pairs_full = 0.0;
     DArr<int32_t> colmap;
+    // per-row tail entry lists of the current head (rebuilt with the B panel)
+    DArr<int32_t> te_cnt, te_item;
+    DArr<float> te_x, row_tail_abs, row_head_sq;
+    DArr<float> row_len;  // Jaccard handles: |I(v)| as float for select.hip
     // double-buffered row-block panels: a producer stream (densify, GEMM, tail) runs one block ahead
     // of the consumer stream (select, re-rank)
     hipStream_t stream2 = nullptr;
@@ -277,8 +281,8 @@ void build_neighbors(knncf_handle* h, int32_t count) {
     Train& tr = h->tr;
     NeighborTable& nt = h->nt;
     if (count <= 0 || nt.kcap <= 0) return;
-    KN_REQUIRE(h->cfg.similarity == KNNCF_SIM_COSINE, KNNCF_E_UNSUPPORTED,
-               "kNN neighbourhoods are built for the adjusted-cosine similarity only");
+    KN_REQUIRE(h->cfg.similarity != KNNCF_SIM_ONE, KNNCF_E_UNSUPPORTED,
+               "kNN neighbourhoods with similarityOne: every similarity is 1.0, the neighbourhood is the first k users in Set order — not built");
     hipStream_t st = h->stream;
     if (count > 256) {
         // longest rows first (LPT): one workgroup per row in select and re-rank, and the row lengths are heavy-tailed
@@ -318,6 +322,17 @@ void build_neighbors(knncf_handle* h, int32_t count) {
         launch_colmap(tr, h->head, h->colmap.p, st);
         h->Bpanel.ensure((size_t)U_pad * h->K_pad);
         launch_densify(tr, nullptr, 0, tr.U, h->colmap.p, h->Bpanel.p, h->K_pad, U_pad, fp16, st);
+        if (tr.jaccard) {
+            // the counting GEMM stores exact integers: fp16 holds them up to 2048 (KNNCF_FLAG_F32_PANEL lifts the limit)
+            KN_REQUIRE(!s_fp16 || h->head <= 2048, KNNCF_E_UNSUPPORTED, "Jaccard: more than 2048 dense head items need KNNCF_FLAG_F32_PANEL");
+            h->row_len.ensure((size_t)row_len_size(tr.U));
+            launch_row_len(tr, h->row_len.p, st);
+        }
+        if (h->head < tr.I) {
+            h->te_cnt.ensure(tr.U); h->te_item.ensure(tr.n); h->te_x.ensure(tr.n);
+            h->row_tail_abs.ensure(tr.U); h->row_head_sq.ensure(tr.U);
+            launch_tail_entries(tr, h->colmap.p, h->te_cnt.p, h->te_item.p, h->te_x.p, h->row_tail_abs.p, h->row_head_sq.p, st);
+        }
         h->b_ready = true;
         KN_HIP(hipMemGetInfo(&free_b, &total_b));
     }
@@ -337,7 +352,7 @@ void build_neighbors(knncf_handle* h, int32_t count) {
         }
         const int64_t n_listed = (int64_t)n_tiles * (n_tiles + 1) / 2;
         Stage s(h, &h->tm.gemm_ms);
-        launch_gemm_sym(h->Bpanel.p, h->S_full.p, s_fp16, U_pad, h->K_pad, h->K_pad, U_pad, fp16, h->sym_tiles.p, n_listed, st);
+        launch_gemm_sym(h->Bpanel.p, h->S_full.p, s_fp16, U_pad, h->K_pad, h->K_pad, U_pad, fp16, !tr.jaccard, h->sym_tiles.p, n_listed, st);
         h->tm.gemm_launches += 1;
         h->tm.gemm_flops_executed += 2.0 * 65536.0 * (double)n_listed * (double)h->K_pad;
         // ordered pairs (row, other user) of the rows actually wanted x the dense columns (bench.py halves it)
@@ -407,7 +422,7 @@ void build_neighbors(knncf_handle* h, int32_t count) {
         }
         if (!use_sym) {
             Stage s(h, &h->tm.gemm_ms, sp);
-            launch_gemm_nt(h->Apanel[slot].p, h->Bpanel.p, h->S[slot].p, s_fp16, M, U_pad, K_pad, K_pad, K_pad, U_pad, fp16, sp);
+            launch_gemm_nt(h->Apanel[slot].p, h->Bpanel.p, h->S[slot].p, s_fp16, M, U_pad, K_pad, K_pad, K_pad, U_pad, fp16, !tr.jaccard, sp);
             h->tm.gemm_launches += 1;
             h->tm.gemm_flops_executed += 2.0 * (double)M * (double)U_pad * (double)K_pad;
             // SURVEY 8(d) per-unit figure x the units this launch processes: ordered pairs (row, other user)
@@ -419,7 +434,8 @@ void build_neighbors(knncf_handle* h, int32_t count) {
         {
             // sparse tail (LDS atomics per row tile) + histogram select, fused: one pass over S
             Stage s(h, &h->tm.select_ms, sc);
-            launch_tail_select(tr, h->colmap.p, head < tr.I, use_sym ? h->S_full.p : h->S[slot].p, use_sym, s_fp16, U_pad, rows, d_rows, nt.k, eps_opnd, eps_rest, cap,
+            TailEntries te{h->te_cnt.p, h->te_item.p, h->te_x.p, h->row_tail_abs.p, h->row_head_sq.p, h->row_len.p};
+            launch_tail_select(tr, h->colmap.p, te, head < tr.I, use_sym ? h->S_full.p : h->S[slot].p, use_sym, s_fp16, U_pad, rows, d_rows, nt.k, eps_opnd, eps_rest, cap,
                                h->sel.cand_idx.p, h->sel.cand_approx.p, h->sel.cand_cnt.p, h->sel.cand_eps.p, h->sel.grp_v0.p, h->sel.grp_x.p, select_gcap(nt.k), sc);
             h->tm.select_launches += 1;
             h->tm.tail_pair_updates += h->tail_pairs_full * ((double)rows / (double)tr.U);
@@ -612,6 +628,7 @@ void do_fit_device(knncf_handle* h, const int32_t* d_users, const int32_t* d_ite
     h->pt_ready = false;
     h->h_ukeys.clear(); h->h_ikeys.clear(); h->h_uid.clear();
     tr.n = n;
+    tr.jaccard = h->cfg.similarity == KNNCF_SIM_JACCARD;
     {
         Stage s(h, &h->tm.prep_ms);
         if (tr.user_raw.p != d_users) {
@@ -960,7 +977,7 @@ int knncf_neighbors(knncf_handle* h, int32_t u, int32_t cap, int32_t* ids, doubl
     return guarded(h, [&] {
         require_fitted(h);
         KN_REQUIRE(count && cap >= 0 && (cap == 0 || (ids && sims)), KNNCF_E_INVALID, "bad output arguments");
-        KN_REQUIRE(h->cfg.similarity == KNNCF_SIM_COSINE, KNNCF_E_UNSUPPORTED, "neighbourhoods: adjusted cosine only");
+        KN_REQUIRE(h->cfg.similarity != KNNCF_SIM_ONE, KNNCF_E_UNSUPPORTED, "neighbourhoods: adjusted cosine or Jaccard");
         int32_t du = dense_user(h, u);
         load_host_ids(h);
         if (du < 0) {  // user absent from train: every similarity is 0.0, ties keep Set order (N3)
@@ -983,7 +1000,7 @@ int knncf_neighbors(knncf_handle* h, int32_t u, int32_t cap, int32_t* ids, doubl
 static void do_neighbors_batch(knncf_handle* h, const int32_t* users, int64_t n, int32_t cap, int32_t* ids, double* sims, int32_t* counts) {
     require_fitted(h);
     KN_REQUIRE(n >= 0 && cap >= 0 && (n == 0 || (users && counts)) && (n == 0 || cap == 0 || (ids && sims)), KNNCF_E_INVALID, "bad arguments");
-    KN_REQUIRE(h->cfg.similarity == KNNCF_SIM_COSINE, KNNCF_E_UNSUPPORTED, "neighbourhoods: adjusted cosine only");
+    KN_REQUIRE(h->cfg.similarity != KNNCF_SIM_ONE, KNNCF_E_UNSUPPORTED, "neighbourhoods: adjusted cosine or Jaccard");
     if (n == 0) return;
     Train& tr = h->tr;
     NeighborTable& nt = h->nt;
@@ -1066,7 +1083,7 @@ int knncf_knn_similarity(knncf_handle* h, int32_t u, int32_t v, double* out) {
     return guarded(h, [&] {
         require_fitted(h);
         KN_REQUIRE(out, KNNCF_E_INVALID, "null out");
-        KN_REQUIRE(h->cfg.similarity == KNNCF_SIM_COSINE, KNNCF_E_UNSUPPORTED, "neighbourhoods: adjusted cosine only");
+        KN_REQUIRE(h->cfg.similarity != KNNCF_SIM_ONE, KNNCF_E_UNSUPPORTED, "neighbourhoods: adjusted cosine or Jaccard");
         int32_t du = dense_user(h, u), dv = dense_user(h, v);
         *out = 0.0;
         if (du < 0 || dv < 0) return;  // all of an unseen user's similarities are 0.0

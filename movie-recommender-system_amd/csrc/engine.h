@@ -75,6 +75,9 @@ struct Train {
     std::vector<int64_t> pop_count;  // host: rater counts in that order
     double global_avg = 0.0;
     int32_t own_lo = 0, own_hi = 0;  // owned dense users [lo, hi)
+    // the handle's similarity is jaccardCoefficient :440-464: the similarity stage then counts common items — 0/1 operand
+    // panels, tail entries of value 1 — instead of summing products of preprocessed ratings
+    bool jaccard = false;
 };
 
 // status word bits written by kernels
@@ -107,19 +110,22 @@ void launch_dense_ids(const Train& tr, const int32_t* d_users, const int32_t* d_
 
 // ---- gemm.hip: densify + K5 ------------------------------------------------------------
 // rows[r] = dense user of panel row r (nullptr: panel row r == user row_begin + r)
+// (tr.jaccard: every present entry is written as 1.0 — the 0/1 panel whose GEMM counts common items)
 void launch_densify(const Train& tr, const int32_t* d_rows, int32_t row_begin, int32_t n_rows,
                     const int32_t* d_colmap, bf16_t* panel, int64_t ld, int64_t panel_rows, bool fp16,
                     hipStream_t st);
 // colmap[item] = column of the dense head panel (popularity rank < H) or -1 (tail)
 void launch_colmap(const Train& tr, int32_t H, int32_t* d_colmap, hipStream_t st);
 // C[M][ldc] (fp32 or fp16) = A[M][K] * B[N][K]^T, 16-bit in / fp32 accumulate; M, N multiples of 128, K of 64
+// clamp: fp16 C entries are clamped to [-1, 1] before rounding (adjusted cosine: the exact value lies there); false for
+// the counting GEMM of the Jaccard path (counts <= 2048 are exact in fp16)
 void launch_gemm_nt(const bf16_t* A, const bf16_t* B, void* C, bool c_fp16, int64_t M, int64_t N, int64_t K,
-                    int64_t lda, int64_t ldb, int64_t ldc, bool fp16, hipStream_t st);
+                    int64_t lda, int64_t ldb, int64_t ldc, bool fp16, bool clamp, hipStream_t st);
 
 // the whole symmetric matrix at once: C[N][ldc] = B B^T computed on and above the diagonal (256 x 256 tiles in the order of
 // the tile list) and mirrored below it; the stored values are bit for bit those of launch_gemm_nt(B, B, ...)
 void gemm_sym_tile_list(int32_t n_tiles, std::vector<uint32_t>& out);
-void launch_gemm_sym(const bf16_t* B, void* C, bool c_fp16, int64_t N, int64_t K, int64_t ldb, int64_t ldc, bool fp16,
+void launch_gemm_sym(const bf16_t* B, void* C, bool c_fp16, int64_t N, int64_t K, int64_t ldb, int64_t ldc, bool fp16, bool clamp,
                      const uint32_t* d_tile_list, int64_t n_listed, hipStream_t st);
 
 // ---- select.hip: K6 + K6b --------------------------------------------------------------
@@ -150,8 +156,21 @@ struct SelectScratch {
 
 // per panel row: S[r][:] += sparse tail (items with colmap < 0), then threshold + shortlist:
 // candidates v with S[r][v] >= T_r - 2 eps_r; eps_r = eps_opnd * ||head part of row r|| + eps_rest + per-row terms
+// per-row tail entry lists for the current head (select.hip: k_tail_entries); device pointers
+struct TailEntries {
+    const int32_t* cnt = nullptr;   // [U]
+    const int32_t* item = nullptr;  // [n], row u's entries at u_ptr[u] ..
+    const float* x = nullptr;       // [n]
+    const float* tail_abs = nullptr;  // [U]
+    const float* head_sq = nullptr;   // [U]
+    const float* row_len = nullptr;   // Jaccard handles: [row_len_size(U)] |I(v)| as float
+};
+int64_t row_len_size(int32_t U);
+void launch_row_len(const Train& tr, float* d_out, hipStream_t st);
+void launch_tail_entries(const Train& tr, const int32_t* d_colmap, int32_t* te_cnt, int32_t* te_item, float* te_x,
+                         float* row_tail_abs, float* row_head_sq, hipStream_t st);
 // s_by_user: S is the whole matrix and row r's similarities are S[d_row_user[r]] (symmetric path); else S[r]
-void launch_tail_select(const Train& tr, const int32_t* d_colmap, bool has_tail, const void* S, bool s_by_user, bool s_fp16, int64_t lds,
+void launch_tail_select(const Train& tr, const int32_t* d_colmap, const TailEntries& te, bool has_tail, const void* S, bool s_by_user, bool s_fp16, int64_t lds,
                         int32_t n_rows, const int32_t* d_row_user, int32_t k, float eps_opnd, float eps_rest, int32_t cap,
                         int32_t* cand_idx, float* cand_approx, int32_t* cand_cnt, float* cand_eps, int32_t* grp_v0, float* grp_x,
                         int32_t gcap, hipStream_t st);

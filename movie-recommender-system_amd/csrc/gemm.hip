@@ -31,7 +31,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 template <bool F16>
 __global__ void k_densify(const int64_t* __restrict__ u_ptr, const int32_t* __restrict__ s_col,
                           const double* __restrict__ s_pre, const int32_t* __restrict__ rows, int32_t row_begin,
-                          int32_t n_rows, const int32_t* __restrict__ colmap, bf16_t* __restrict__ panel, int64_t ld) {
+                          int32_t n_rows, const int32_t* __restrict__ colmap, bf16_t* __restrict__ panel, int64_t ld, int ones) {
     // one wave per panel row
     int32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     int32_t lane = threadIdx.x & 63;
@@ -42,8 +42,9 @@ __global__ void k_densify(const int64_t* __restrict__ u_ptr, const int32_t* __re
     for (int64_t p = b + lane; p < e; p += 64) {
         int32_t c = colmap ? colmap[s_col[p]] : s_col[p];
         if (c >= 0) {
-            if (F16) reinterpret_cast<_Float16*>(out)[c] = (_Float16)(float)s_pre[p];
-            else out[c] = (bf16_t)(float)s_pre[p];
+            const float x = ones ? 1.0f : (float)s_pre[p];  // (ones: the 0/1 panel of the Jaccard path)
+            if (F16) reinterpret_cast<_Float16*>(out)[c] = (_Float16)x;
+            else out[c] = (bf16_t)x;
         }
     }
 }
@@ -53,8 +54,8 @@ void launch_densify(const Train& tr, const int32_t* d_rows, int32_t row_begin, i
     KN_HIP(hipMemsetAsync(panel, 0, (size_t)panel_rows * ld * sizeof(bf16_t), st));
     if (n_rows <= 0) return;
     int blocks = (int)ceil_div((int64_t)n_rows * 64, 256);
-    if (fp16) k_densify<true><<<blocks, 256, 0, st>>>(tr.u_ptr.p, tr.s_col.p, tr.s_pre.p, d_rows, row_begin, n_rows, d_colmap, panel, ld);
-    else k_densify<false><<<blocks, 256, 0, st>>>(tr.u_ptr.p, tr.s_col.p, tr.s_pre.p, d_rows, row_begin, n_rows, d_colmap, panel, ld);
+    if (fp16) k_densify<true><<<blocks, 256, 0, st>>>(tr.u_ptr.p, tr.s_col.p, tr.s_pre.p, d_rows, row_begin, n_rows, d_colmap, panel, ld, tr.jaccard ? 1 : 0);
+    else k_densify<false><<<blocks, 256, 0, st>>>(tr.u_ptr.p, tr.s_col.p, tr.s_pre.p, d_rows, row_begin, n_rows, d_colmap, panel, ld, tr.jaccard ? 1 : 0);
     KN_HIP(hipGetLastError());
 }
 
@@ -144,7 +145,8 @@ struct EpiGeom {
 template <bool F16, class OT, int WM, int WN, int WAVES_M, int WAVES_N, bool SYM>
 __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64)
 k_gemm_nt_bf16(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, OT* __restrict__ C, int tiles_m,
-               int tiles_n, int k_tiles, int64_t lda, int64_t ldb, int64_t ldc, const uint32_t* __restrict__ tile_list, int n_listed) {
+               int tiles_n, int k_tiles, int64_t lda, int64_t ldb, int64_t ldc, const uint32_t* __restrict__ tile_list, int n_listed,
+               float clamp_hi) {
     constexpr int WAVES = WAVES_M * WAVES_N;
     constexpr int TBM = WAVES_M * WM * 32, TBN = WAVES_N * WN * 32;
     static_assert(TBM == TBN, "square block tiles: both operand tiles share one staging routine");
@@ -291,7 +293,7 @@ k_gemm_nt_bf16(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, OT* _
                                     typedef __attribute__((ext_vector_type(4))) _Float16 h4;
                                     h4 v;
 #pragma unroll
-                                    for (int e = 0; e < 4; ++e) v[e] = (_Float16)fminf(fmaxf(acc[i][j][4 * g + e], -1.0f), 1.0f);  // (see api.cpp: eps_rest)
+                                    for (int e = 0; e < 4; ++e) v[e] = (_Float16)fminf(fmaxf(acc[i][j][4 * g + e], -clamp_hi), clamp_hi);  // (1.0: see api.cpp eps_rest; 65504 for counts)
                                     *reinterpret_cast<h4*>(dst) = v;
                                 } else {
                                     *reinterpret_cast<float4*>(dst) = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
@@ -326,7 +328,7 @@ k_gemm_nt_bf16(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, OT* _
                                         const int i = i0 + ii;
                                         const int col = wc * (WN * 32) + j * 32 + 8 * g + 4 * fhalf + e;
                                         OT* dst = reinterpret_cast<OT*>(img + col * RS_T) + (ii * 32 + frow);
-                                        if (ESZ == 2) *dst = (OT)fminf(fmaxf(acc[i][j][4 * g + e], -1.0f), 1.0f);
+                                        if (ESZ == 2) *dst = (OT)fminf(fmaxf(acc[i][j][4 * g + e], -clamp_hi), clamp_hi);
                                         else *dst = (OT)acc[i][j][4 * g + e];
                                     }
                     }
@@ -353,7 +355,7 @@ k_gemm_nt_bf16(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, OT* _
 
 template <bool F16, class OT, int WM, int WN, int WAVES_M, int WAVES_N, bool SYM>
 static void launch_gemm_cfg(const bf16_t* A, const bf16_t* B, OT* C, int64_t M, int64_t N, int64_t K, int64_t lda,
-                            int64_t ldb, int64_t ldc, const uint32_t* tile_list, int64_t n_listed, hipStream_t st) {
+                            int64_t ldb, int64_t ldc, const uint32_t* tile_list, int64_t n_listed, bool clamp, hipStream_t st) {
     constexpr int TB = WAVES_M * WM * 32;
     constexpr int SMEM = EpiGeom<OT, WM, WAVES_M, TB>::SMEM;
     static_assert(SMEM <= 160 * 1024, "gemm: LDS plan exceeds the CU's 160 KiB");
@@ -373,30 +375,30 @@ static void launch_gemm_cfg(const bf16_t* A, const bf16_t* B, OT* C, int64_t M, 
     });
     const unsigned grid = (unsigned)(tiles < slots ? tiles : slots);
     k_gemm_nt_bf16<F16, OT, WM, WN, WAVES_M, WAVES_N, SYM><<<grid, WAVES_M * WAVES_N * 64, SMEM, st>>>(
-        A, B, C, (int)(M / TB), (int)(N / TB), (int)(K / BK), lda, ldb, ldc, tile_list, (int)n_listed);
+        A, B, C, (int)(M / TB), (int)(N / TB), (int)(K / BK), lda, ldb, ldc, tile_list, (int)n_listed, clamp ? 1.0f : 65504.0f);
     KN_HIP(hipGetLastError());
 }
 
 template <bool F16, class OT>
 static void launch_gemm_t(const bf16_t* A, const bf16_t* B, OT* C, int64_t M, int64_t N, int64_t K, int64_t lda,
-                          int64_t ldb, int64_t ldc, hipStream_t st) {
+                          int64_t ldb, int64_t ldc, bool clamp, hipStream_t st) {
     // (a 4-wave variant of the large tile, each wave a 128 x 128 sub-tile in 256 accumulator registers — a third
     // less LDS read traffic per flop — measured the same: 30.6 vs 30.7 ms at K = 448, 52.8 vs 51.9 ms at K = 1024)
     static const bool force_small = getenv("KNNCF_GEMM_TILE128") != nullptr;  // A/B switch for measurements
     // (16 waves on the 256 x 256 tile, each a 64 x 64 sub-tile, 4 waves per SIMD: 8.3 vs 6.9 ms per launch at K = 256)
-    if (M % 256 == 0 && N % 256 == 0 && !force_small) launch_gemm_cfg<F16, OT, 4, 2, 2, 4, false>(A, B, C, M, N, K, lda, ldb, ldc, nullptr, 0, st);
-    else launch_gemm_cfg<F16, OT, 2, 2, 2, 2, false>(A, B, C, M, N, K, lda, ldb, ldc, nullptr, 0, st);
+    if (M % 256 == 0 && N % 256 == 0 && !force_small) launch_gemm_cfg<F16, OT, 4, 2, 2, 4, false>(A, B, C, M, N, K, lda, ldb, ldc, nullptr, 0, clamp, st);
+    else launch_gemm_cfg<F16, OT, 2, 2, 2, 2, false>(A, B, C, M, N, K, lda, ldb, ldc, nullptr, 0, clamp, st);
 }
 
 // C is fp16 (c_fp16) or fp32; operands fp16 (fp16) or bf16.  M, N multiples of 128 (256 selects the large tile)
 void launch_gemm_nt(const bf16_t* A, const bf16_t* B, void* C, bool c_fp16, int64_t M, int64_t N, int64_t K, int64_t lda,
-                    int64_t ldb, int64_t ldc, bool fp16, hipStream_t st) {
+                    int64_t ldb, int64_t ldc, bool fp16, bool clamp, hipStream_t st) {
     KN_REQUIRE(M % 128 == 0 && N % 128 == 0 && K % BK == 0 && K > 0, KNNCF_E_INVALID, "gemm: shape not tile-aligned");
     KN_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, KNNCF_E_INVALID, "gemm: leading dimensions must be multiples of 8");
-    if (fp16 && c_fp16) launch_gemm_t<true, _Float16>(A, B, static_cast<_Float16*>(C), M, N, K, lda, ldb, ldc, st);
-    else if (fp16) launch_gemm_t<true, float>(A, B, static_cast<float*>(C), M, N, K, lda, ldb, ldc, st);
-    else if (c_fp16) launch_gemm_t<false, _Float16>(A, B, static_cast<_Float16*>(C), M, N, K, lda, ldb, ldc, st);
-    else launch_gemm_t<false, float>(A, B, static_cast<float*>(C), M, N, K, lda, ldb, ldc, st);
+    if (fp16 && c_fp16) launch_gemm_t<true, _Float16>(A, B, static_cast<_Float16*>(C), M, N, K, lda, ldb, ldc, clamp, st);
+    else if (fp16) launch_gemm_t<true, float>(A, B, static_cast<float*>(C), M, N, K, lda, ldb, ldc, clamp, st);
+    else if (c_fp16) launch_gemm_t<false, _Float16>(A, B, static_cast<_Float16*>(C), M, N, K, lda, ldb, ldc, clamp, st);
+    else launch_gemm_t<false, float>(A, B, static_cast<float*>(C), M, N, K, lda, ldb, ldc, clamp, st);
 }
 
 // the 256 x 256 tiles on and above the diagonal of an n_tiles x n_tiles grid, 8 tile rows at a time and column by
@@ -411,13 +413,13 @@ void gemm_sym_tile_list(int32_t n_tiles, std::vector<uint32_t>& out) {
 
 // S[N x N] = B B^T for all N rows at once, N a multiple of 256, computed on and above the diagonal and mirrored
 // (fp16 panel storage only: the path that holds the whole similarity matrix)
-void launch_gemm_sym(const bf16_t* B, void* C, bool c_fp16, int64_t N, int64_t K, int64_t ldb, int64_t ldc, bool fp16,
+void launch_gemm_sym(const bf16_t* B, void* C, bool c_fp16, int64_t N, int64_t K, int64_t ldb, int64_t ldc, bool fp16, bool clamp,
                      const uint32_t* d_tile_list, int64_t n_listed, hipStream_t st) {
     KN_REQUIRE(N % 256 == 0 && N / 256 < 65536 && K % BK == 0 && K > 0 && ldb % 8 == 0 && ldc % 8 == 0, KNNCF_E_INVALID, "symmetric gemm: shape not tile-aligned");
-    if (fp16 && c_fp16) launch_gemm_cfg<true, _Float16, 4, 2, 2, 4, true>(B, B, static_cast<_Float16*>(C), N, N, K, ldb, ldb, ldc, d_tile_list, n_listed, st);
-    else if (fp16) launch_gemm_cfg<true, float, 4, 2, 2, 4, true>(B, B, static_cast<float*>(C), N, N, K, ldb, ldb, ldc, d_tile_list, n_listed, st);
-    else if (c_fp16) launch_gemm_cfg<false, _Float16, 4, 2, 2, 4, true>(B, B, static_cast<_Float16*>(C), N, N, K, ldb, ldb, ldc, d_tile_list, n_listed, st);
-    else launch_gemm_cfg<false, float, 4, 2, 2, 4, true>(B, B, static_cast<float*>(C), N, N, K, ldb, ldb, ldc, d_tile_list, n_listed, st);
+    if (fp16 && c_fp16) launch_gemm_cfg<true, _Float16, 4, 2, 2, 4, true>(B, B, static_cast<_Float16*>(C), N, N, K, ldb, ldb, ldc, d_tile_list, n_listed, clamp, st);
+    else if (fp16) launch_gemm_cfg<true, float, 4, 2, 2, 4, true>(B, B, static_cast<float*>(C), N, N, K, ldb, ldb, ldc, d_tile_list, n_listed, clamp, st);
+    else if (c_fp16) launch_gemm_cfg<false, _Float16, 4, 2, 2, 4, true>(B, B, static_cast<_Float16*>(C), N, N, K, ldb, ldb, ldc, d_tile_list, n_listed, clamp, st);
+    else launch_gemm_cfg<false, float, 4, 2, 2, 4, true>(B, B, static_cast<float*>(C), N, N, K, ldb, ldb, ldc, d_tile_list, n_listed, clamp, st);
 }
 
 }  // namespace knncf

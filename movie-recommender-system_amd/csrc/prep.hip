@@ -501,7 +501,7 @@ __global__ void k_pack_records(int64_t n, const int32_t* __restrict__ s_user, co
 
 __global__ void k_item_major(int64_t n, const uint32_t* __restrict__ perm_iu, const uint4* __restrict__ rec,
                              int32_t* __restrict__ it_user, uint32_t* __restrict__ it_pack,
-                             double* __restrict__ it_dev, uint32_t* __restrict__ it_t) {
+                             double* __restrict__ it_dev, uint32_t* __restrict__ it_t, int ones) {
     int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n) return;
     uint32_t p = perm_iu[q];
@@ -516,6 +516,7 @@ __global__ void k_item_major(int64_t n, const uint32_t* __restrict__ perm_iu, co
        // spends no instruction on it.
         int32_t qv = __double2int_rn(pre * 65536.0);
         qv = min(max(qv, -65536), 65535);
+        if (ones) qv = 1;  // Jaccard handles count common items: every tail entry weighs 1 (select.hip reads the counts out unscaled)
         const uint32_t c = (uint32_t)user & (uint32_t)(SELECT_TCOLS - 1);
         const uint32_t cell = (((c >> 3) << 2) | (c & 3u)) + ((c & 4u) ? (uint32_t)(SELECT_TCOLS / 2) : 0u);
         it_pack[q] = (cell << 17) | ((uint32_t)qv & 0x1ffffu);
@@ -643,7 +644,7 @@ void prep_commit(Train& tr, PrepScratch& sc, hipStream_t st) {
     sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.v32_a.p, sc.v32_b.p, n, bits_for(I), st);
     sc.rec.ensure(2 * (size_t)n);
     k_pack_records<<<nblocks(n), TPB, 0, st>>>(n, tr.s_user.p, tr.s_pre.p, tr.s_dev.p, tr.s_t.p, sc.rec.p);
-    k_item_major<<<nblocks(n), TPB, 0, st>>>(n, sc.v32_b.p, sc.rec.p, tr.it_user.p, tr.it_pack.p, tr.it_dev.p, tr.it_t.p);
+    k_item_major<<<nblocks(n), TPB, 0, st>>>(n, sc.v32_b.p, sc.rec.p, tr.it_user.p, tr.it_pack.p, tr.it_dev.p, tr.it_t.p, tr.jaccard ? 1 : 0);
     tr.tile_stride = (int32_t)ceil_div(tr.U, SELECT_TCOLS) + 1;
     tr.it_tile.ensure((size_t)I * tr.tile_stride);
     k_item_tiles<<<nblocks((int64_t)I * tr.tile_stride), TPB, 0, st>>>(I, tr.tile_stride, tr.i_ptr.p, tr.it_user.p, tr.it_tile.p);

@@ -118,6 +118,21 @@ __device__ __forceinline__ double pair_sim(const Rows& R, int32_t u, int32_t v, 
     return owner_dot(R, u, v);
 }
 
+// jaccardCoefficient :446-463: |I(u) & I(v)| / (|I(u)| + |I(v)| - |I(u) & I(v)|), Double / Int; no summation order involved
+__device__ __forceinline__ double jaccard_sim(const Rows& R, int32_t u, int32_t v) {
+    int64_t pa = R.u_ptr[u], pb = R.u_ptr[v];
+    const int64_t ea = R.u_ptr[u + 1], eb = R.u_ptr[v + 1];
+    const int64_t nu = ea - pa, nv = eb - pb;
+    int64_t both = 0;
+    while (pa < ea && pb < eb) {
+        const int32_t ca = R.s_col[pa], cb = R.s_col[pb];
+        if (ca == cb) { ++both; ++pa; ++pb; }
+        else if (ca < cb) ++pa;
+        else ++pb;
+    }
+    return (double)both / (double)(nu + nv - both);
+}
+
 __device__ __forceinline__ bool ranks_before(double sa, int32_t ia, double sb, int32_t ib) {
     return sa > sb || (sa == sb && ia < ib);
 }
@@ -183,7 +198,8 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 typedef const __attribute__((address_space(3))) u32x2* lds_cu32x2;
 typedef __attribute__((address_space(3))) u32x2* lds_u32x2;
 
-template <class PreP>
+// JAC: every hit contributes 1.0 (the fold then yields the exact number of common items)
+template <bool JAC, class PreP>
 __device__ __forceinline__ double wave_sims(const Rows& R, lds_cu32x2 bp, PreP upre, int32_t nu, lds_f64 wb, lds_u32 meta,
                                             uint32_t my_b, uint32_t my_len, int n_c, int lane) {
     lds_u32x2 cpair = (lds_u32x2)meta;  // [64] (end of candidate j in the stream, entry of stream position 0 of j)
@@ -264,7 +280,7 @@ __device__ __forceinline__ double wave_sims(const Rows& R, lds_cu32x2 bp, PreP u
                     mask[k] = __ballot(hit);
                     // position of item c in u's row (for a miss: some position of the row, its value is not used)
                     const int32_t idx = min((int32_t)(wp[k].y + __popc(wp[k].x & ((1u << (c & 31u)) - 1u))), nu - 1);
-                    prod[k] = upre[idx] * __hiloint2double((int)py[g + k].y, (int)py[g + k].x);
+                    prod[k] = JAC ? 1.0 : upre[idx] * __hiloint2double((int)py[g + k].y, (int)py[g + k].x);
                 }
 #pragma unroll
                 for (int k = 0; k < GRP; ++k) {
@@ -282,7 +298,7 @@ __device__ __forceinline__ double wave_sims(const Rows& R, lds_cu32x2 bp, PreP u
     return acc;
 }
 
-template <int TILE>
+template <int TILE, bool JAC>
 __global__ void __launch_bounds__(TPB) k_rerank(Rows R, const int64_t* __restrict__ seq, int32_t n_rows,
                                                 const int32_t* __restrict__ row_user, int32_t cap,
                                                 const int32_t* __restrict__ cand_idx, const float* __restrict__ cand_approx,
@@ -387,9 +403,12 @@ __global__ void __launch_bounds__(TPB) k_rerank(Rows R, const int64_t* __restric
             // Set1..Set4 iterate in file order and the memo history matters (N2, N6): scalar path
             row_entries += len_v;  // algorithmic traffic of this kernel: the candidates' rows (12 B per entry)
             const bool small_v = (lane < n_c) && (len_v <= 4);
-            if (nu > 4 && !__any(small_v)) {
-                s = pre_lds ? wave_sims(R, (lds_cu32x2)bp, (lds_cf64)upre, nu, wb, meta, b_v, len_v, n_c, lane)
-                            : wave_sims(R, (lds_cu32x2)bp, R.s_pre + ub, nu, wb, meta, b_v, len_v, n_c, lane);
+            if (JAC) {  // exact count of common items (no order involved, any row length), then :461
+                const double both = wave_sims<true>(R, (lds_cu32x2)bp, (lds_cf64)upre, nu, wb, meta, b_v, len_v, n_c, lane);
+                s = both / (double)((int64_t)nu + (int64_t)len_v - (int64_t)both);
+            } else if (nu > 4 && !__any(small_v)) {
+                s = pre_lds ? wave_sims<false>(R, (lds_cu32x2)bp, (lds_cf64)upre, nu, wb, meta, b_v, len_v, n_c, lane)
+                            : wave_sims<false>(R, (lds_cu32x2)bp, R.s_pre + ub, nu, wb, meta, b_v, len_v, n_c, lane);
             } else {
                 s = (lane < n_c) ? pair_sim(R, u, v, seq_u, seq[v]) : 0.0;
             }
@@ -482,7 +501,7 @@ __global__ void __launch_bounds__(1024) k_sum_row_entries(int32_t n_rows, const 
     if (threadIdx.x == 0 && part) atomicAdd(total, part);
 }
 
-template <int TILE>
+template <int TILE, bool JAC>
 static void launch_rerank_tile(const Rows& R, const Train& tr, NeighborTable& nt, int32_t n_rows, const int32_t* d_row_user,
                                int32_t cap, const int32_t* cand_idx, const float* cand_approx, const int32_t* cand_cnt,
                                const float* cand_eps, double* d_stats, uint32_t* d_row_entries, hipStream_t st) {
@@ -491,8 +510,8 @@ static void launch_rerank_tile(const Rows& R, const Train& tr, NeighborTable& nt
                         (size_t)words * 8 + (size_t)(TPB / 64) * WMETA * 4;
     KN_REQUIRE(smem <= 160 * 1024 - 2048, KNNCF_E_UNSUPPORTED, "re-rank: item bitmap does not fit in LDS (too many items)");
     static PerDeviceState lds_state;
-    ensure_dynamic_lds(lds_state, (const void*)k_rerank<TILE>, smem);
-    k_rerank<TILE><<<n_rows, TPB, smem, st>>>(R, nt.seq.p, n_rows, d_row_user, cap, cand_idx, cand_approx, cand_cnt, nt.kcap,
+    ensure_dynamic_lds(lds_state, (const void*)k_rerank<TILE, JAC>, smem);
+    k_rerank<TILE, JAC><<<n_rows, TPB, smem, st>>>(R, nt.seq.p, n_rows, d_row_user, cap, cand_idx, cand_approx, cand_cnt, nt.kcap,
                                               nt.kcap, nt.idx.p, nt.sim.p, nt.cnt.p, cand_eps, d_stats, d_row_entries, words);
     k_sum_row_entries<<<(unsigned)ceil_div(n_rows, 1024), 1024, 0, st>>>(n_rows, d_row_entries, reinterpret_cast<unsigned long long*>(d_stats) + 1);
     KN_HIP(hipGetLastError());
@@ -509,23 +528,28 @@ void launch_rerank(const Train& tr, NeighborTable& nt, int32_t n_rows, const int
     KN_REQUIRE(nt.kcap <= 1024, KNNCF_E_UNSUPPORTED, "k > 1024 is not supported by the re-rank kernel yet");
     Rows R{tr.u_ptr.p, tr.s_col.p, tr.s_t.p, tr.s_pre.p, (uint32_t)(tr.n * 4), (uint32_t)(tr.n * 8)};
     const float* apx = verify ? cand_approx : nullptr;
-    if (nt.kcap <= 512) launch_rerank_tile<1024>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
-    else launch_rerank_tile<2048>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
+    if (tr.jaccard) {
+        if (nt.kcap <= 512) launch_rerank_tile<1024, true>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
+        else launch_rerank_tile<2048, true>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
+    } else {
+        if (nt.kcap <= 512) launch_rerank_tile<1024, false>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
+        else launch_rerank_tile<2048, false>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
+    }
 }
 
 // exact similarities of one user against everyone (out[user] = -inf): the fallback for rows whose
 // shortlist overflowed and the engine behind scalar queries
 __global__ void k_exact_row(Rows R, const int64_t* __restrict__ seq, int32_t U, int32_t user, int64_t user_seq,
-                            double* __restrict__ out) {
+                            double* __restrict__ out, int jaccard) {
     int32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= U) return;
-    out[v] = (v == user) ? -INFINITY : pair_sim(R, user, v, user_seq, seq[v]);
+    out[v] = (v == user) ? -INFINITY : (jaccard ? jaccard_sim(R, user, v) : pair_sim(R, user, v, user_seq, seq[v]));
 }
 
 void launch_exact_row(const Train& tr, const NeighborTable& nt, int32_t user, int64_t user_seq, double* d_out,
                       hipStream_t st) {
     Rows R{tr.u_ptr.p, tr.s_col.p, tr.s_t.p, tr.s_pre.p, (uint32_t)(tr.n * 4), (uint32_t)(tr.n * 8)};
-    k_exact_row<<<(unsigned)ceil_div(tr.U, TPB), TPB, 0, st>>>(R, nt.seq.p, tr.U, user, user_seq, d_out);
+    k_exact_row<<<(unsigned)ceil_div(tr.U, TPB), TPB, 0, st>>>(R, nt.seq.p, tr.U, user, user_seq, d_out, tr.jaccard ? 1 : 0);
     KN_HIP(hipGetLastError());
 }
 
@@ -550,18 +574,8 @@ __global__ void __launch_bounds__(TPB) k_full_rows(Rows R, int32_t U, int32_t* _
         const int32_t v = v0 + threadIdx.x;
         double s = 0.0;
         if (v < U) {
-            if (JACCARD) {  // jaccardCoefficient :446-463: |I(u) & I(v)| / (|I(u)| + |I(v)| - |I(u) & I(v)|)
-                int64_t pa = pa0, pb = R.u_ptr[v];
-                const int64_t eb = R.u_ptr[v + 1];
-                const int64_t nv = eb - pb;
-                int64_t both = 0;
-                while (pa < ea && pb < eb) {
-                    const int32_t ca = R.s_col[pa], cb = R.s_col[pb];
-                    if (ca == cb) { ++both; ++pa; ++pb; }
-                    else if (ca < cb) ++pa;
-                    else ++pb;
-                }
-                s = (double)both / (double)((ea - pa0) + nv - both);
+            if (JACCARD) {
+                s = jaccard_sim(R, u, v);
             } else {
                 s = merge_dot(R, u, v);
             }

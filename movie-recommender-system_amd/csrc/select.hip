@@ -86,7 +86,81 @@ struct TailArgs {
     const uint32_t* it_tile;  // [I][tile_stride]: first entry of the item's list with user >= t * TCOLS
     int32_t tile_stride;
     int32_t has_tail;
+    // per-row tail entry lists (k_tail_entries below, rebuilt whenever the head changes): the row's tail entries compacted to
+    // the front of its position range, so that a row (or a 256-entry chunk of it) is ONE coalesced read instead of the
+    // chain s_col -> colmap -> LDS slot atomic; and the two per-row sums of the error band
+    const int32_t* te_cnt;   // [U] tail entries of the row
+    const int32_t* te_item;  // [n] item of the j-th tail entry of row u at u_ptr[u] + j
+    const float* te_x;       // [n] pre(u, item) * 2^8
+    const float* row_tail_abs;  // [U] sum over the row's tail entries of |pre(u, i)|
+    const float* row_head_sq;   // [U] sum over the row's head entries of pre(u, i)^2
+    const float* row_len;       // Jaccard handles: [U rounded up to a tile + a tile] |I(v)| as float (1.0 in the padding)
 };
+
+// one wave per user: the row's tail entries (colmap < 0) in position order, compacted to the front of the row's range; the
+// sums in a fixed order (position -> lane, then xor shuffles), so that the error band is the same on every run
+__global__ void k_tail_entries(int32_t U, const int64_t* __restrict__ u_ptr, const int32_t* __restrict__ s_col,
+                               const double* __restrict__ s_pre, const int32_t* __restrict__ colmap, int32_t* __restrict__ te_cnt,
+                               int32_t* __restrict__ te_item, float* __restrict__ te_x, float* __restrict__ row_tail_abs,
+                               float* __restrict__ row_head_sq, int ones) {
+    const int32_t u = (int32_t)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int lane = threadIdx.x & 63;
+    if (u >= U) return;
+    const int64_t ub = u_ptr[u], ue = u_ptr[u + 1];
+    float tail_abs = 0.f, head_sq = 0.f;
+    int32_t n_out = 0;
+    for (int64_t p0 = ub; p0 < ue; p0 += 64) {
+        const int64_t p = p0 + lane;
+        bool is_tail = false;
+        int32_t item = 0;
+        float x = 0.f;
+        if (p < ue) {
+            item = s_col[p];
+            x = (float)s_pre[p];
+            is_tail = colmap[item] < 0;
+            if (is_tail) tail_abs += fabsf(x);
+            else head_sq = __builtin_fmaf(x, x, head_sq);
+        }
+        const unsigned long long m = __ballot(is_tail);
+        if (is_tail) {
+            const int32_t slot = n_out + __popcll(m & ((1ull << lane) - 1ull));
+            te_item[ub + slot] = item;
+            te_x[ub + slot] = ones ? 1.0f : x * 256.0f;  // (ones: Jaccard handles count — factor 1 x entry value 1)
+        }
+        n_out += __popcll(m);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        tail_abs += __shfl_xor(tail_abs, o);
+        head_sq += __shfl_xor(head_sq, o);
+    }
+    if (lane == 0) {
+        te_cnt[u] = n_out;
+        row_tail_abs[u] = tail_abs;
+        row_head_sq[u] = head_sq;
+    }
+}
+
+void launch_tail_entries(const Train& tr, const int32_t* d_colmap, int32_t* te_cnt, int32_t* te_item, float* te_x,
+                         float* row_tail_abs, float* row_head_sq, hipStream_t st) {
+    k_tail_entries<<<(unsigned)ceil_div((int64_t)tr.U * 64, 256), 256, 0, st>>>(tr.U, tr.u_ptr.p, tr.s_col.p, tr.s_pre.p, d_colmap, te_cnt,
+                                                                                te_item, te_x, row_tail_abs, row_head_sq, tr.jaccard ? 1 : 0);
+    KN_HIP(hipGetLastError());
+}
+
+// |I(v)| of every user as float, 1.0 in the padding (Jaccard handles: the denominators of select.hip's approximate values)
+__global__ void k_row_len(int64_t n_out, int32_t U, const int64_t* __restrict__ u_ptr, float* __restrict__ out) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < n_out) out[v] = v < U ? (float)(u_ptr[v + 1] - u_ptr[v]) : 1.0f;
+}
+
+int64_t row_len_size(int32_t U) { return round_up(U, SELECT_TCOLS) + SELECT_TCOLS; }
+
+void launch_row_len(const Train& tr, float* d_out, hipStream_t st) {
+    const int64_t n_out = row_len_size(tr.U);
+    k_row_len<<<(unsigned)ceil_div(n_out, 256), 256, 0, st>>>(n_out, tr.U, tr.u_ptr.p, d_out);
+    KN_HIP(hipGetLastError());
+}
 
 // threshold from the cumulative histogram: lower edge of the bin holding the kk-th largest value seen so
 // far, minus 2 eps (-inf while fewer than kk values have been seen).  Thread t owns bins [4t, 4t+4).
@@ -160,7 +234,11 @@ struct Raw8<_Float16> {
     }
 };
 
-template <class ST>
+// JAC: the handle's similarity is the Jaccard coefficient :440-464.  Panel + tail then hold exact COUNTS of common items
+// (0/1 operands, tail entries of value 1, read out unscaled) and every column's value becomes
+// count / (|I(u)| + |I(v)| - count) in fp32 before the thresholds see it: both operands are exact integers below 2^24, so
+// the quotient is the correctly rounded fp32 image of the exact similarity and the error band is a few 1e-7.
+template <class ST, bool JAC>
 __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ S, int32_t s_by_user, int64_t ld, int32_t n_rows,
                                                      const int32_t* __restrict__ row_user, TailArgs T, int32_t U,
                                                      int32_t kk, float eps_opnd, float eps_rest, int32_t cap, int32_t* __restrict__ cand_idx,
@@ -215,59 +293,35 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
     if (threadIdx.x == 0) { s_count = 0; s_ne = 0; s_thr = -INFINITY; }
     __syncthreads();
 
-    // tail entries of the row, EMAX row positions (a "chunk") at a time.  Rows of up to EMAX ratings (all but the
-    // heaviest raters) collect them once; longer rows re-collect every chunk for every tile.
-    const int n_chunks = T.has_tail ? (int)((ue - ub + EMAX - 1) / EMAX) : 0;
+    // tail entries of the row, EMAX of them (a "chunk") at a time, straight out of the row's precomputed list.  Rows of up
+    // to EMAX tail entries (all but the heaviest raters) take them once; longer rows re-read a chunk for every tile.
+    const int32_t n_te = T.has_tail ? T.te_cnt[u] : 0;
+    const int n_chunks = (n_te + EMAX - 1) / EMAX;
     const int n_tiles = T.tile_stride - 1;
     const bool reg_counts = n_chunks == 1 && n_tiles <= MAXT;
     auto collect = [&](int ch) {
-        const int64_t cb = ub + (int64_t)ch * EMAX, ce = min(ue, cb + EMAX);
-        for (int64_t p = cb + threadIdx.x; p < ce; p += TPB) {
-            const int32_t item = T.s_col[p];
-            if (T.colmap[item] < 0) {
-                const int32_t slot = atomicAdd(&s_ne, 1);
-                e_item[slot] = item;
-                e_x[slot] = (float)T.s_pre[p] * TAIL_FIX;
-            }
+        const int32_t c0 = ch * EMAX, cn = min(EMAX, n_te - c0);
+        for (int32_t j = threadIdx.x; j < cn; j += TPB) {
+            e_item[j] = T.te_item[ub + c0 + j];
+            e_x[j] = T.te_x[ub + c0 + j];
         }
+        if (threadIdx.x == 0) s_ne = cn;
     };
-    // Two per-row quantities of the error band, summed in a fixed order (position -> thread, then shuffles) so that
-    // the band is the same on every run:
+    // Two per-row quantities of the error band (k_tail_entries):
     //  * tail_abs = sum over the row's tail entries of |pre(u, i)|: the Q0.16 rater-side factors err by 2^-16 each;
     //  * head_sq  = sum over the row's HEAD entries of pre(u, i)^2: the operand roundings of the dense part err by
     //    (2u + u^2) sum_head |x y| <= (2u + u^2) ||x_head|| ||y_head|| <= (2u + u^2) ||x_head||   (||y|| <= 1).
-    float tail_abs = 0.f, head_sq = 0.f;
-    if (n_chunks > 0) {
-        for (int64_t p = ub + threadIdx.x; p < ue; p += TPB) {
-            const float x = (float)T.s_pre[p];
-            if (T.colmap[T.s_col[p]] < 0) tail_abs += fabsf(x);
-            else head_sq = __builtin_fmaf(x, x, head_sq);
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            tail_abs += __shfl_xor(tail_abs, o);
-            head_sq += __shfl_xor(head_sq, o);
-        }
-        if (lane == 0) {
-            reinterpret_cast<float*>(wtot)[wave] = tail_abs;
-            reinterpret_cast<float*>(e_b0)[wave] = head_sq;  // (idle until the first setup)
-        }
+    float tail_abs = 0.f;
+    float head_norm = 1.0f;  // no tail: every item is a head column
+    if (T.has_tail) {
+        tail_abs = T.row_tail_abs[u];
+        head_norm = fminf(1.0f, sqrtf(T.row_head_sq[u]) * 1.0001f + 1e-6f);  // (fp32 summation slack)
     }
     if (n_chunks == 1) collect(0);
     __syncthreads();
-    float head_norm = 1.0f;  // no tail: every item is a head column
-    if (n_chunks > 0) {
-        tail_abs = 0.f;
-        head_sq = 0.f;
-        for (int w = 0; w < TPB / 64; ++w) {
-            tail_abs += reinterpret_cast<const float*>(wtot)[w];
-            head_sq += reinterpret_cast<const float*>(e_b0)[w];
-        }
-        head_norm = fminf(1.0f, sqrtf(head_sq) * 1.0001f + 1e-6f);  // (fp32 summation slack)
-    }
-    const float eps = row_eps(eps_opnd * head_norm + eps_rest, ue - ub) + tail_abs * (1.0001f / 65536.0f);
+    const float eps = JAC ? 4e-7f : row_eps(eps_opnd * head_norm + eps_rest, ue - ub) + tail_abs * (1.0001f / 65536.0f);
     if (threadIdx.x == 0) cand_eps[r] = eps;
-    const bool any_tail = n_chunks > 1 || (n_chunks == 1 && s_ne > 0);
+    const bool any_tail = n_chunks > 0;
     // single-chunk rows: thread e owns entry e for the whole row.  Its item's rater counts per tile (<= 32768 each)
     // are packed into registers, so the tile loop needs no global read for the ranges
     const uint32_t* my_tb = T.it_tile;
@@ -576,9 +630,7 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
             use_tables(0);
             for (int ch = 0; ch < n_chunks; ++ch) {
                 if (n_chunks > 1) {
-                    __syncthreads();
-                    if (threadIdx.x == 0) s_ne = 0;
-                    __syncthreads();
+                    __syncthreads();  // the previous chunk's tables are no longer read
                     collect(ch);
                     __syncthreads();
                 }
@@ -607,10 +659,25 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
                 const int4 a = *lo4, b = *hi4;
                 *lo4 = make_int4(0, 0, 0, 0);
                 *hi4 = make_int4(0, 0, 0, 0);
-                sx[8 * j + 0] = __builtin_fmaf((float)a.x, TAIL_UNFIX, sx[8 * j + 0]); sx[8 * j + 1] = __builtin_fmaf((float)a.y, TAIL_UNFIX, sx[8 * j + 1]);
-                sx[8 * j + 2] = __builtin_fmaf((float)a.z, TAIL_UNFIX, sx[8 * j + 2]); sx[8 * j + 3] = __builtin_fmaf((float)a.w, TAIL_UNFIX, sx[8 * j + 3]);
-                sx[8 * j + 4] = __builtin_fmaf((float)b.x, TAIL_UNFIX, sx[8 * j + 4]); sx[8 * j + 5] = __builtin_fmaf((float)b.y, TAIL_UNFIX, sx[8 * j + 5]);
-                sx[8 * j + 6] = __builtin_fmaf((float)b.z, TAIL_UNFIX, sx[8 * j + 6]); sx[8 * j + 7] = __builtin_fmaf((float)b.w, TAIL_UNFIX, sx[8 * j + 7]);
+                constexpr float UNFIX = JAC ? 1.0f : TAIL_UNFIX;  // (Jaccard: the cells hold counts)
+                sx[8 * j + 0] = __builtin_fmaf((float)a.x, UNFIX, sx[8 * j + 0]); sx[8 * j + 1] = __builtin_fmaf((float)a.y, UNFIX, sx[8 * j + 1]);
+                sx[8 * j + 2] = __builtin_fmaf((float)a.z, UNFIX, sx[8 * j + 2]); sx[8 * j + 3] = __builtin_fmaf((float)a.w, UNFIX, sx[8 * j + 3]);
+                sx[8 * j + 4] = __builtin_fmaf((float)b.x, UNFIX, sx[8 * j + 4]); sx[8 * j + 5] = __builtin_fmaf((float)b.y, UNFIX, sx[8 * j + 5]);
+                sx[8 * j + 6] = __builtin_fmaf((float)b.z, UNFIX, sx[8 * j + 6]); sx[8 * j + 7] = __builtin_fmaf((float)b.w, UNFIX, sx[8 * j + 7]);
+            }
+        }
+        if (JAC) {  // counts -> Jaccard coefficients (the masked columns stay -inf)
+            const float nu_f = (float)(ue - ub);
+#pragma unroll
+            for (int j = 0; j < NG; ++j) {
+                const float4* lp = reinterpret_cast<const float4*>(T.row_len + (int64_t)t0 + 8 * (threadIdx.x + TPB * j));
+                const float4 la = lp[0], lb = lp[1];
+                const float len8[8] = {la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float c = sx[8 * j + i];
+                    sx[8 * j + i] = c > -INFINITY ? c / (nu_f + len8[i] - c) : c;
+                }
             }
         }
         PH(6);  // read-out
@@ -761,14 +828,14 @@ void select_profile_dump() {
 }
 #endif
 
-template <class ST>
+template <class ST, bool JAC>
 static void launch_tail_select_t(const TailArgs& T, const ST* S, bool s_by_user, int64_t lds, int32_t n_rows, const int32_t* d_row_user,
                                  int32_t U, int32_t kk, float eps_opnd, float eps_rest, int32_t cap, int32_t* cand_idx, float* cand_approx,
                                  int32_t* cand_cnt, float* cand_eps, int32_t* grp_v0, float* grp_x, int32_t gcap, hipStream_t st) {
     const size_t smem = (size_t)TCOLS * 4 + (size_t)NBINS * 4 + (size_t)EMAX * 4 + 2 * ((size_t)EMAX * 12 + (size_t)PMAX * 2) + (2 * (TPB / 64) + 4 + 64) * 4;  // + 64 scratch cells
     static PerDeviceState lds_state;
-    ensure_dynamic_lds(lds_state, (const void*)k_tail_select<ST>, smem);
-    k_tail_select<ST><<<n_rows, TPB, smem, st>>>(S, s_by_user ? 1 : 0, lds, n_rows, d_row_user, T, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap);
+    ensure_dynamic_lds(lds_state, (const void*)k_tail_select<ST, JAC>, smem);
+    k_tail_select<ST, JAC><<<n_rows, TPB, smem, st>>>(S, s_by_user ? 1 : 0, lds, n_rows, d_row_user, T, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap);
     KN_HIP(hipGetLastError());
 #ifdef KNNCF_SELECT_PROFILE
     KN_HIP(hipStreamSynchronize(st));
@@ -776,7 +843,7 @@ static void launch_tail_select_t(const TailArgs& T, const ST* S, bool s_by_user,
 #endif
 }
 
-void launch_tail_select(const Train& tr, const int32_t* d_colmap, bool has_tail, const void* S, bool s_by_user, bool s_fp16, int64_t lds,
+void launch_tail_select(const Train& tr, const int32_t* d_colmap, const TailEntries& te, bool has_tail, const void* S, bool s_by_user, bool s_fp16, int64_t lds,
                         int32_t n_rows, const int32_t* d_row_user, int32_t k, float eps_opnd, float eps_rest, int32_t cap,
                         int32_t* cand_idx, float* cand_approx, int32_t* cand_cnt, float* cand_eps, int32_t* grp_v0, float* grp_x,
                         int32_t gcap, hipStream_t st) {
@@ -790,9 +857,17 @@ void launch_tail_select(const Train& tr, const int32_t* d_colmap, bool has_tail,
     // kernel costs without the tail machinery: the panel scan, the thresholds, the group store)
     static const bool skip_tail = getenv("KNNCF_DEBUG_SKIP_TAIL") != nullptr;
     if (skip_tail) has_tail = false;
-    TailArgs T{tr.u_ptr.p, tr.s_col.p, tr.s_pre.p, d_colmap, tr.i_ptr.p, tr.it_pack.p, (uint32_t)(tr.n * 4), tr.it_tile.p, tr.tile_stride, has_tail ? 1 : 0};
-    if (s_fp16) launch_tail_select_t(T, static_cast<const _Float16*>(S), s_by_user, lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, st);
-    else launch_tail_select_t(T, static_cast<const float*>(S), s_by_user, lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, st);
+    KN_REQUIRE(!has_tail || (te.cnt && te.item && te.x && te.tail_abs && te.head_sq), KNNCF_E_STATE, "select: tail entry lists missing");
+    TailArgs T{tr.u_ptr.p, tr.s_col.p, tr.s_pre.p, d_colmap, tr.i_ptr.p, tr.it_pack.p, (uint32_t)(tr.n * 4), tr.it_tile.p, tr.tile_stride, has_tail ? 1 : 0,
+               te.cnt, te.item, te.x, te.tail_abs, te.head_sq, te.row_len};
+    if (tr.jaccard) {
+        KN_REQUIRE(te.row_len != nullptr, KNNCF_E_STATE, "select: row lengths missing");
+        if (s_fp16) launch_tail_select_t<_Float16, true>(T, static_cast<const _Float16*>(S), s_by_user, lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, st);
+        else launch_tail_select_t<float, true>(T, static_cast<const float*>(S), s_by_user, lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, st);
+    } else {
+        if (s_fp16) launch_tail_select_t<_Float16, false>(T, static_cast<const _Float16*>(S), s_by_user, lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, st);
+        else launch_tail_select_t<float, false>(T, static_cast<const float*>(S), s_by_user, lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, st);
+    }
 }
 
 }  // namespace knncf

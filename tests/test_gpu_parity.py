@@ -155,6 +155,96 @@ def test_personalized_cosine_and_jaccard_ml100k_shape(kn, oracle, synth):
         e.close()
 
 
+@pytest.mark.parametrize("head", [0, 64, 0xFFFFFFFF])
+def test_knn_with_the_jaccard_coefficient(kn, oracle, syn100k, head):
+    """getSimilarity(train, k, jaccardCoefficient(train)) — the k-nearest-neighbour closures over the reference's other
+    similarity (shared/predictions.scala:440-464, :596-649) — through the SAME pipeline as the adjusted cosine: the 0/1
+    operand panel's MFMA GEMM and the tail's LDS atomics count the common items exactly, select.hip turns the counts into
+    count / (|I(u)| + |I(v)| - count) in fp32, the re-rank recomputes the shortlist exactly (fp64 quotient of exact
+    integers).  Jaccard values tie massively; ties are broken by Set order like everywhere else (N3).  Every split of the
+    items into dense head and sparse tail must give the same neighbours."""
+    d = syn100k
+    tr = (d.train.users, d.train.items, d.train.ratings)
+    te = (d.test.users, d.test.items, d.test.ratings)
+    m = oracle.Model(*tr)
+    users = np.unique(d.train.users)
+    for k in (10, 300):
+        e = _engine(kn, tr, k=k, sim=kn.SIM_JACCARD, flags=kn.FLAG_VERIFY_BOUND, head_items=head)
+        p = m.pipeline(oracle.SIM_JACCARD, k)
+        want, preds = p.mae(*te, True)
+        got = e.mae(kn.PRED_KNN, *te)
+        np.testing.assert_array_equal(e.predict_batch(kn.PRED_KNN, te[0], te[1]), preds)
+        assert abs(got - want) <= MAE_TOL
+        ids, sims, counts = e.neighbors_batch(users[::5])
+        for row, u in enumerate(users[::5]):
+            oids, osims = p.neighbors(int(u))
+            assert ids[row, :counts[row]].tolist() == oids.tolist(), f"user {u} k {k}"
+            assert sims[row, :counts[row]].tolist() == osims.tolist()
+        assert e.knn_similarity(int(users[0]), int(users[0])) == 0.0
+        t = e.timings()
+        assert t["max_bound_violation"] <= 0.0 and t["gemm_launches"] >= 1
+        e.close()
+
+
+@pytest.mark.parametrize("symmetric", [True, False])
+def test_jaccard_knn_beyond_the_personalized_table(kn, oracle, synth, symmetric, monkeypatch):
+    """U = 20 000 (the U x U table of PERSONALIZED stops at 2048 users): Jaccard neighbourhoods through the counting GEMM —
+    the symmetric launch and the row-block launches — two column tiles per row, sampled users and their predictions bit
+    for bit against the oracle's per-pair closures"""
+    if not symmetric:
+        monkeypatch.setenv("KNNCF_DEBUG_NO_SYMMETRIC_GEMM", "1")
+    d = synth.syn_scaled(20_000, 3_000, 1_500_000, seed=41, half_stars=True)
+    tr = (d.train.users, d.train.items, d.train.ratings)
+    te = (d.test.users, d.test.items, d.test.ratings)
+    k = 50
+    e = _engine(kn, tr, k=k, sim=kn.SIM_JACCARD, flags=kn.FLAG_VERIFY_BOUND)
+    preds = e.predict_batch(kn.PRED_KNN, te[0], te[1])
+    t = e.timings()
+    assert t["max_bound_violation"] <= 0.0 and t["fallback_rows"] == 0
+    assert t["gemm_launches"] == (1 if symmetric else t["select_launches"])
+    p = oracle.Model(*tr).pipeline(oracle.SIM_JACCARD, k)
+    users = np.unique(d.train.users)
+    sample = users[:: len(users) // 24]
+    ids, sims, counts = e.neighbors_batch(sample)
+    for row, u in enumerate(sample):
+        oids, osims = p.neighbors(int(u))
+        assert ids[row, :counts[row]].tolist() == oids.tolist(), f"user {u}"
+        assert sims[row, :counts[row]].tolist() == osims.tolist()
+    mask = np.isin(te[0], sample)
+    _, opreds = p.mae(te[0][mask], te[1][mask], te[2][mask], True)
+    np.testing.assert_array_equal(preds[mask], opreds)
+    e.close()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_jaccard_knn_random_small_cases(kn, oracle, seed):
+    """tiny inputs, users with <= 4 ratings included (the Jaccard coefficient has no summation order to depend on),
+    unknown users and items among the test rows"""
+    rng = np.random.default_rng(900 + seed)
+    rows = _random_case(rng, n_users=14 + 4 * seed, n_items=19, n_ratings=90 + 15 * seed, half=(seed % 2 == 1), tiny_rows=seed % 3)
+    cut = len(rows) * 4 // 5
+    train, test = rows[:cut], rows[cut:]
+    if not _no_zero_scale(train):
+        pytest.skip("scale() == 0 corner")
+    test += [(999_999, train[0][1], 3.0), (train[0][0], 888_888, 4.0)]
+    tr, te = _cols(train), _cols(test)
+    m = oracle.Model(*tr)
+    users = sorted(set(tr[0]))
+    for k in (1, 3, len(users) + 2):
+        e = _engine(kn, tr, k=k, sim=kn.SIM_JACCARD, flags=kn.FLAG_VERIFY_BOUND)
+        p = m.pipeline(oracle.SIM_JACCARD, k)
+        want, preds = p.mae(*te, True)
+        np.testing.assert_array_equal(e.predict_batch(kn.PRED_KNN, te[0], te[1]), preds)
+        assert e.mae(kn.PRED_KNN, *te) == pytest.approx(want, abs=1e-13)
+        for u in users:
+            ids, sims = e.neighbors(u)
+            oids, osims = p.neighbors(u)
+            assert ids.tolist() == oids.tolist(), f"user {u} k {k}"
+            assert sims.tolist() == osims.tolist()
+        assert e.timings()["max_bound_violation"] <= 0.0
+        e.close()
+
+
 def test_recommendations_equal_oracle(kn, oracle, synth):
     """recommendations :651-674: ids and predictions bit for bit, ml-100k shape, the Recommender's
     n = 3 and a longer list; kNN k = 300 (recommend/Recommender.scala:85-88), the baseline, and the all-ties case"""
