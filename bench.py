@@ -131,6 +131,8 @@ def main():
     ap.add_argument("--workload", default="syn-25m")
     ap.add_argument("--k", type=int, default=300)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1: nccl (= RCCL, the product path) or gloo "
+                    "(rehearsal of the N > 1 host path with several ranks sharing one GPU; collectives staged through the host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16-leg", action="store_true", help="skip the extra (untimed) bf16-operand steps reported beside the fp16 default")
     ap.add_argument("--head-items", type=int, default=0, help="dense head width of the hybrid similarity (0 = cost model)")
@@ -148,14 +150,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)  # nccl == RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend=args.backend)
 
     # the in-tree library is prebuilt; if anything is stale, ONE rank rebuilds it while the others wait
     if rank == 0:
@@ -176,7 +182,7 @@ def main():
     d_te = (torch.from_numpy(te.users).to(device), torch.from_numpy(te.items).to(device), torch.from_numpy(te.ratings).to(device))
     torch.cuda.synchronize()
 
-    eng = kn.Engine(k=args.k, similarity=kn.SIM_COSINE, device=local_rank, shard_rank=rank, shard_count=world,
+    eng = kn.Engine(k=args.k, similarity=kn.SIM_COSINE, device=dev_index, shard_rank=rank, shard_count=world,
                     head_items=args.head_items, flags=args.engine_flags, workspace_bytes=args.workspace_bytes)
     model = sharded.ShardedKnn(sharded.DeviceEngineAdapter(eng, device), dist, rank, world)
 
@@ -203,7 +209,7 @@ def main():
     elapsed = time.perf_counter() - t_start
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        sharded._all_reduce(dist, tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     step_ms = np.diff(np.array([t_start] + step_end)) * 1e3
     tm = eng.timings()
@@ -313,7 +319,7 @@ def main():
         if world == 1 and not args.no_bf16_leg and not (args.engine_flags & 4):
             # north_star says bf16 operands; the default is fp16 (same MFMA rate, 8x narrower error band, identical
             # results).  The bf16 number of the same build, outside the timed region:
-            eb = kn.Engine(k=args.k, similarity=kn.SIM_COSINE, device=local_rank, head_items=args.head_items,
+            eb = kn.Engine(k=args.k, similarity=kn.SIM_COSINE, device=dev_index, head_items=args.head_items,
                            flags=args.engine_flags | kn.FLAG_BF16_FILTER)
             mb = sharded.ShardedKnn(sharded.DeviceEngineAdapter(eb, device), None, 0, 1)
             mb.fit(*d_tr)

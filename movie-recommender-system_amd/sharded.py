@@ -66,6 +66,31 @@ def user_block(num_users, rank, world):
     return min(per * rank, num_users), min(per * (rank + 1), num_users)
 
 
+def _staged(dist, t):
+    """gloo rehearsals of the multi-GPU path (several ranks sharing one GPU, or CPU tests): gloo moves host memory, so
+    device tensors are staged through the host; with nccl (RCCL over xGMI) tensors travel as they are."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def _all_gather_into(dist, recv, send):
+    if _staged(dist, send):
+        r = recv.cpu()
+        dist.all_gather_into_tensor(r, send.cpu())
+        recv.copy_(r)
+    else:
+        dist.all_gather_into_tensor(recv, send)
+
+
+def _all_reduce(dist, t, op=None):
+    kw = {} if op is None else {"op": op}
+    if _staged(dist, t):
+        c = t.cpu()
+        dist.all_reduce(c, **kw)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, **kw)
+
+
 def _all_gather_segments(dist, arrays, lo, hi, ranges):
     """In-place all-gather of arrays[j][lo_r:hi_r] from every rank r.  Segments differ in length, so
     they travel in one padded all_gather_into_tensor per call (bigger, fewer collectives)."""
@@ -80,7 +105,7 @@ def _all_gather_segments(dist, arrays, lo, hi, ranges):
     for j, a in enumerate(arrays):
         send[j * seg: j * seg + (hi - lo)] = a[lo:hi]
     recv = torch.empty(world * k * seg, dtype=send.dtype, device=send.device)
-    dist.all_gather_into_tensor(recv, send)
+    _all_gather_into(dist, recv, send)
     for r, (l, h) in enumerate(ranges):
         if (l, h) == (lo, hi):
             continue
@@ -122,7 +147,7 @@ class ShardedKnn:
 
         code = 0 if err is None else int(getattr(err, "status", -1)) or -1
         flag = torch.tensor([code], dtype=torch.int64, device=device)
-        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)   # status codes are negative: MIN = "the worst"
+        _all_reduce(self.dist, flag, op=self.dist.ReduceOp.MIN)   # status codes are negative: MIN = "the worst"
         worst = int(flag.item())
         if err is not None:
             raise err
@@ -138,7 +163,7 @@ class ShardedKnn:
         dev = t["user_avg"].device
         mine = torch.tensor([ulo, uhi, nlo, nhi], dtype=torch.int64, device=dev)
         allr = torch.empty(4 * self.world, dtype=torch.int64, device=dev)
-        self.dist.all_gather_into_tensor(allr, mine)
+        _all_gather_into(self.dist, allr, mine)
         allr = allr.cpu().view(self.world, 4).tolist()
         _all_gather_segments(self.dist, [t["user_avg"], t["user_norm"]], ulo, uhi, [(a, b) for a, b, _, _ in allr])
         _all_gather_segments(self.dist, [t["dev"], t["pre"]], nlo, nhi, [(c, d) for _, _, c, d in allr])
@@ -154,6 +179,6 @@ class ShardedKnn:
         s, c = self.engine.mae_device(predictor, users, items, ratings)
         if self.world > 1:
             buf = torch.tensor([s, float(c)], dtype=torch.float64, device=users.device)
-            self.dist.all_reduce(buf)
+            _all_reduce(self.dist, buf)
             s, c = float(buf[0].item()), int(round(buf[1].item()))
         return (s / c if c else float("nan")), c
