@@ -308,8 +308,17 @@ void build_neighbors(knncf_handle* h, int32_t count) {
     // 288 GB of HBM hold it easily at the ml-25m shape (53 GB as fp16); shapes whose square does not fit (syn-1M: 2 TB)
     // and partial / sharded builds take the row-block path.
     const size_t sym_bytes = (size_t)U_pad * (size_t)U_pad * (size_t)s_elem;
-    const bool use_sym = h->cfg.shard_count == 1 && (int64_t)count * 2 >= tr.U && U_pad / 256 < 65536 &&
-                         sym_bytes <= (free_b + h->S_full.bytes()) / 3 && !getenv("KNNCF_DEBUG_NO_SYMMETRIC_GEMM");
+    bool use_sym = h->cfg.shard_count == 1 && (int64_t)count * 2 >= tr.U && U_pad / 256 < 65536 &&
+                   sym_bytes <= (free_b + h->S_full.bytes()) / 3 && !getenv("KNNCF_DEBUG_NO_SYMMETRIC_GEMM");
+    if (use_sym) {
+        try {
+            h->S_full.ensure((sym_bytes + 3) / 4);
+        } catch (const Error& e) {  // (fragmented / shared device: the row-block path needs far less in one piece)
+            if (e.status != KNNCF_E_NOMEM) throw;
+            (void)hipGetLastError();
+            use_sym = false;
+        }
+    }
     if (!h->b_ready) {
         // hybrid similarity: the H most-rated items are dense MFMA columns, the rest a sparse tail
         h->head = choose_head(h, count, use_sym);
@@ -340,7 +349,6 @@ void build_neighbors(knncf_handle* h, int32_t count) {
     const int32_t head = h->head;
     h->tm.head_items = head;
     if (use_sym) {
-        h->S_full.ensure((sym_bytes + 3) / 4);
         const int32_t n_tiles = (int32_t)(U_pad / 256);
         if (h->sym_tiles_n != n_tiles) {
             std::vector<uint32_t> list;

@@ -265,7 +265,6 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
     float& s_thr = *reinterpret_cast<float*>(wtot + TPB / 64);
     uint32_t& s_count = wtot[TPB / 64 + 1];
     int32_t& s_ne = *reinterpret_cast<int32_t*>(wtot + TPB / 64 + 2);
-    uint32_t& s_next = wtot2[TPB / 64];  // (first of the 64 spare cells behind wtot2) next undealt piece of the tile
     const int32_t r = blockIdx.x;
     if (r >= n_rows) return;
 #ifdef KNNCF_SELECT_PROFILE
@@ -405,13 +404,6 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
         const uint32_t wv = __builtin_amdgcn_readfirstlane(wave);
         p_lo = (uint32_t)(((uint64_t)P * wv) / (TPB / 64));
         p_hi = (uint32_t)(((uint64_t)P * (wv + 1)) / (TPB / 64));
-#ifdef KNNCF_SEL_DYNAMIC
-        // dynamic dealing: the waves take windows of KNNCF_SEL_DYNAMIC pieces off a shared counter (reset here, between the
-        // barrier that ends the previous drain and the one that opens the next)
-        if (threadIdx.x == 0) s_next = 0;
-        p_lo = 0;
-        p_hi = P;
-#endif
     };
     auto use_tables = [&](int buf) {
         e_b = e_b0 + buf * EMAX;
@@ -420,11 +412,7 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
         piece_e = piece_e0 + buf * PMAX;
     };
     auto window = [&](uint32_t pw) {  // lane l looks up the entry of piece pw + l and keeps its descriptor
-#ifdef KNNCF_SEL_DYNAMIC
-        n_here = min((uint32_t)KNNCF_SEL_DYNAMIC, p_hi - pw);
-#else
         n_here = min(64u, p_hi - pw);
-#endif
         // lanes past the window's pieces hold a NULL piece (one lane, factor 0.0: it adds 0 to the cell of entry 0), so
         // that the drain below only ever runs whole groups
         d_q = 0;
@@ -548,21 +536,10 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
 #ifdef KNNCF_ABL_NODRAIN  /* timing-only ablation: everything but the drain itself */
         return;
 #endif
-#ifdef KNNCF_SEL_DYNAMIC
-        for (;;) {
-            uint32_t pw = 0;
-            if (lane == 0) pw = atomicAdd(&s_next, (uint32_t)KNNCF_SEL_DYNAMIC);
-            pw = __builtin_amdgcn_readfirstlane(pw);
-            if (pw >= p_hi) break;
-            window(pw);
-            tail_window(__builtin_amdgcn_readfirstlane((n_here + 7u) & ~7u));
-        }
-#else
         for (uint32_t pw = p_lo; pw < p_hi; pw += 64) {
             window(pw);
             tail_window(__builtin_amdgcn_readfirstlane((n_here + 7u) & ~7u));
         }
-#endif
     };
     const bool pipelined = any_tail && n_chunks == 1;  // single-chunk rows: tile t + 1 is set up inside tile t
     if (pipelined) {
@@ -751,11 +728,7 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
         // the store is filling up (wide error bands, e.g. bf16 operands)
         {
             const uint32_t prov = s_count;  // (block-uniform after the barrier)
-#ifdef KNNCF_SEL_NOREFRESH
-            if (prov > next_refresh && prov <= (uint32_t)GCAP && t0 + TCOLS < U) {
-#else
             if ((tile_no == 1 || tile_no == 3 || tile_no == 6 || prov > next_refresh) && prov <= (uint32_t)GCAP && t0 + TCOLS < U) {
-#endif
                 rebuild_hist(s_thr);
                 block_threshold(hist, wtot, &s_thr, kk, eps);
                 next_refresh = max(next_refresh, prov + (uint32_t)GCAP / 8);  // (the store is not compacted: refresh again only after it has grown)
