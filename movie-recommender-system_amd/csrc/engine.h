@@ -14,7 +14,10 @@ typedef __bf16 bf16_t;
 // columns of a similarity row that select.hip holds in LDS at a time (prep.hip tabulates the tile crossings)
 // provisional store of select.hip per similarity row: groups of 8 columns (36 B each); the capacity scales with k
 inline int32_t select_gcap(int32_t k) { return 8192 * (int32_t)((k + 511) / 512 > 1 ? (k + 511) / 512 : 1); }
-static constexpr int SELECT_TCOLS = 16384;  // <= 2^15: it_pack keeps the LDS cell of the column inside its tile in 15 bits
+#ifndef KNNCF_TCOLS
+#define KNNCF_TCOLS 16384  // (A/B switch: 8192 = half-size tiles, three workgroups of k_tail_select per CU)
+#endif
+static constexpr int SELECT_TCOLS = KNNCF_TCOLS;  // <= 2^15: it_pack keeps the LDS cell of the column inside its tile in 15 bits
 
 // ---- sort_util.hip (rocPRIM device radix sort / unique; K0 plumbing only) ---------------
 struct SortWorkspace {

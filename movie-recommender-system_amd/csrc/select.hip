@@ -50,7 +50,8 @@ static constexpr int NG = CPT / 8;
 static_assert(CPT <= 32, "the survivor mask of a thread is one 32-bit word");
 static constexpr int EMAX = 256;     // row positions whose tail entries (16 B each) are held in LDS at a time
 static constexpr int PMAX = 1024;    // pieces per (chunk, tile) with a direct piece -> entry table in LDS
-static constexpr int MAXT = 16;      // tiles whose per-entry rater counts are packed into registers
+static constexpr int MAXT = TCOLS >= 16384 ? 16 : 24;  // tiles whose per-entry rater counts are packed into registers
+static constexpr int WAVES_PER_EU = TCOLS >= 16384 ? 4 : 6;  // two / three 512-thread workgroups per CU (LDS: 79 / 47 KiB each)
 static constexpr int TAIL_G = 8;           // pieces per group of the drain (two groups in flight per wave)
 // the tail is accumulated in Q7.24 fixed point with integer LDS atomics (ds_add_u32; the float form
 // ds_add_f32 measured ~1.4x slower here): |sum| <= 1, each product is quantised with error <= 2^-25,
@@ -239,7 +240,7 @@ struct Raw8<_Float16> {
 // count / (|I(u)| + |I(v)| - count) in fp32 before the thresholds see it: both operands are exact integers below 2^24, so
 // the quotient is the correctly rounded fp32 image of the exact similarity and the error band is a few 1e-7.
 template <class ST, bool JAC>
-__global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ S, int32_t s_by_user, int64_t ld, int32_t n_rows,
+__global__ void __launch_bounds__(TPB, WAVES_PER_EU) k_tail_select(const ST* __restrict__ S, int32_t s_by_user, int64_t ld, int32_t n_rows,
                                                      const int32_t* __restrict__ row_user, TailArgs T, int32_t U,
                                                      int32_t kk, float eps_opnd, float eps_rest, int32_t cap, int32_t* __restrict__ cand_idx,
                                                      float* __restrict__ cand_approx, int32_t* __restrict__ cand_cnt,
@@ -669,9 +670,9 @@ __global__ void __launch_bounds__(2 * TPB) k_tail_select(const ST* __restrict__ 
             // of any set of maxima over disjoint column sets is a lower bound of the kk-th largest value of the row,
             // and a tight one (the top values sit in different threads) — with one histogram atomic per maximum
             // instead of one per column.
-            if (kk <= (TCOLS / 32) / 3) {  // maxima over 4 groups = 32 columns: 1024 of them
+            if (NG >= 4 && kk <= (TCOLS / 32) / 3) {  // maxima over 4 groups = 32 columns
 #pragma unroll
-                for (int j = 0; j < NG; j += 4) {
+                for (int j = 0; j + 3 < NG; j += 4) {
                     const float m = fmaxf(fmaxf(gm[j], gm[j + 1]), fmaxf(gm[j + 2], gm[j + 3]));
                     if (m > -INFINITY) atomicAdd(&hist[sim_bin(m)], 1u);
                 }
