@@ -42,6 +42,10 @@ struct Train {
     // dense ids: trie keys of the distinct raw ids, in dense order (see dense_lookup)
     DArr<uint32_t> ukeys, ikeys;
     DArr<int32_t> uid, iid;  // raw id of dense index
+    // raw id -> dense index as a direct table (MovieLens ids are small non-negative integers): one gather per row instead
+    // of a hash + binary search; empty (n = 0) when an id is negative or >= 2^24 — then dense_lookup is used
+    DArr<int32_t> u_table, i_table;
+    int32_t u_table_n = 0, i_table_n = 0;
     // canonical user-major order ("position" p): users ascending, inside a user items ascending.
     // dense item index == rank in HashSet iteration order, so ascending p inside a user IS the
     // reference's summation order N2 for users with > 4 ratings.
@@ -93,6 +97,7 @@ struct PrepScratch {
     DArr<int32_t> du_row, di_row;
     DArr<uint32_t> perm_f;
     DArr<uint32_t> status;  // [4] device status words
+    DArr<int32_t> idrange;  // [4] min / max raw user id, min / max raw item id
     DArr<double> dsum;      // small reduction scratch
     DArr<uint4> rec;        // [2 n] (preprocessed rating, deviation | user, file row) records: one 32-byte gather per entry
     // side streams for the three independent item folds of prep_commit (created on first use)
