@@ -428,6 +428,28 @@ def test_wide_shape_takes_the_large_u_paths(kn, oracle, synth):
     e.close()
 
 
+def test_ids_outside_the_direct_tables(kn, oracle, synth, monkeypatch):
+    """raw ids that are negative or >= 2^24 (not MovieLens, but legal Ints for `load`) take the general id path: every row's
+    key sorted + unique, hash + binary search per row; and the same path forced on ordinary ids"""
+    d = synth.syn_scaled(300, 120, 9_000, seed=5, half_stars=True)
+    big = lambda a, off: (a.astype(np.int64) * 7919 + off).astype(np.int32)
+    tr = (big(d.train.users, -40_000), big(d.train.items, 1 << 25), d.train.ratings)
+    te = (big(d.test.users, -40_000), big(d.test.items, 1 << 25), d.test.ratings)
+    for force, (a, b) in ((False, (tr, te)), (True, ((d.train.users, d.train.items, d.train.ratings), (d.test.users, d.test.items, d.test.ratings)))):
+        if force:
+            monkeypatch.setenv("KNNCF_DEBUG_NO_ID_TABLES", "1")
+        e = _engine(kn, a, k=20)
+        p = oracle.Model(*a).pipeline(oracle.SIM_COSINE, 20)
+        want, preds = p.mae(*b, True)
+        np.testing.assert_array_equal(e.predict_batch(kn.PRED_KNN, b[0], b[1]), preds)
+        assert abs(e.mae(kn.PRED_KNN, *b) - want) <= MAE_TOL
+        for u in np.unique(a[0])[::37]:
+            ids, sims = e.neighbors(int(u))
+            oids, osims = p.neighbors(int(u))
+            assert ids.tolist() == oids.tolist() and sims.tolist() == osims.tolist()
+        e.close()
+
+
 def test_prediction_without_item_bitmaps(kn, oracle, synth, monkeypatch):
     """shapes whose rater bitmaps would not fit in HBM predict through binary searches (k_predict_knn): forced here"""
     monkeypatch.setenv("KNNCF_DEBUG_NO_ITEM_BITMAPS", "1")
