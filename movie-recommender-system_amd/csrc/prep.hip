@@ -649,7 +649,13 @@ k_item_bits_rank(int32_t I, int64_t words, const int64_t* __restrict__ i_ptr, co
     __shared__ unsigned long long cell[TPB / 64][64];
     const int32_t item = (int32_t)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int lane = threadIdx.x & 63;
-    const bool live = item < I;  // (no early return: the block's waves share the barriers below)
+    const bool live = item < I;
+    // (every wave works on its own item and its own 64 LDS words: the phases below are ordered inside the wave only —
+    //  workgroup barriers made unrelated waves wait for each other's rater lists: 1.07 -> 0.6 ms)
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
     unsigned long long* my = cell[threadIdx.x >> 6];
     int64_t q = live ? i_ptr[item] : 0;
     const int64_t qe = live ? i_ptr[item + 1] : 0;
@@ -658,7 +664,7 @@ k_item_bits_rank(int32_t I, int64_t words, const int64_t* __restrict__ i_ptr, co
     uint32_t run = 0;
     for (int64_t w0 = 0; w0 < words; w0 += 64) {
         my[lane] = 0;
-        __syncthreads();
+        wave_sync();
         const int64_t v_end = (w0 + 64) * 64;  // users below v_end belong to this chunk or an earlier (finished) one
         for (;;) {
             const int64_t p = q + lane;
@@ -669,7 +675,7 @@ k_item_bits_rank(int32_t I, int64_t words, const int64_t* __restrict__ i_ptr, co
             q += c;
             if (c < 64) break;
         }
-        __syncthreads();
+        wave_sync();
         const unsigned long long word = my[lane];
         const uint32_t c = (uint32_t)__popcll(word);
         const uint32_t incl = wave_incl_scan(c);
@@ -679,7 +685,7 @@ k_item_bits_rank(int32_t I, int64_t words, const int64_t* __restrict__ i_ptr, co
             r[w] = run + incl - c;
         }
         run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        __syncthreads();  // (the words are cleared again at the top)
+        wave_sync();  // (the words are cleared again at the top)
     }
 }
 
