@@ -98,6 +98,12 @@ __global__ void k_table_keys(int32_t cells, const int32_t* __restrict__ table, u
     if (present) keys[base + __popcll(m & ((1ull << lane) - 1ull))] = int_trie_key(r);
 }
 
+// raw id of every dense index, read off a resolved direct table (one thread per cell instead of one store per rating)
+__global__ void k_raw_ids_of_table(int32_t cells, const int32_t* __restrict__ table, int32_t* __restrict__ out) {
+    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < cells && table[r] >= 0) out[table[r]] = r;
+}
+
 __global__ void k_dense_ids_table(int64_t n, const int32_t* __restrict__ users, const int32_t* __restrict__ items,
                                   const int32_t* __restrict__ u_table, int32_t u_cells, const int32_t* __restrict__ i_table,
                                   int32_t i_cells, int32_t* __restrict__ du, int32_t* __restrict__ di) {
@@ -506,8 +512,13 @@ void prep_fit(Train& tr, PrepScratch& sc, int32_t shard_rank, int32_t shard_coun
     }
     launch_dense_ids(tr, tr.user_raw.p, tr.item_raw.p, n, sc.du_row.p, sc.di_row.p, st);
     tr.uid.alloc(U); tr.iid.alloc(I);
-    k_scatter_raw_ids<<<nblocks(n), TPB, 0, st>>>(n, tr.user_raw.p, sc.du_row.p, tr.uid.p);
-    k_scatter_raw_ids<<<nblocks(n), TPB, 0, st>>>(n, tr.item_raw.p, sc.di_row.p, tr.iid.p);
+    if (small_ids) {
+        k_raw_ids_of_table<<<nblocks(tr.u_table_n), TPB, 0, st>>>(tr.u_table_n, tr.u_table.p, tr.uid.p);
+        k_raw_ids_of_table<<<nblocks(tr.i_table_n), TPB, 0, st>>>(tr.i_table_n, tr.i_table.p, tr.iid.p);
+    } else {
+        k_scatter_raw_ids<<<nblocks(n), TPB, 0, st>>>(n, tr.user_raw.p, sc.du_row.p, tr.uid.p);
+        k_scatter_raw_ids<<<nblocks(n), TPB, 0, st>>>(n, tr.item_raw.p, sc.di_row.p, tr.iid.p);
+    }
     KN_HIP(hipGetLastError());
 
     const int ubits = bits_for(U), ibits = bits_for(I);
@@ -645,24 +656,31 @@ __global__ void k_item_major(int64_t n, const uint32_t* __restrict__ perm_iu, co
 // exactly once (no memset, no global atomics: 20 M scattered 8-byte atomics were 1 ms at ml-25m shape).
 __global__ void __launch_bounds__(TPB)
 k_item_bits_rank(int32_t I, int64_t words, const int64_t* __restrict__ i_ptr, const int32_t* __restrict__ it_user,
-                 unsigned long long* __restrict__ bits, uint32_t* __restrict__ rank) {
+                 const uint32_t* __restrict__ it_tile, int32_t tile_stride, unsigned long long* __restrict__ bits,
+                 uint32_t* __restrict__ rank) {
+    // One wave per (item, column tile of SELECT_TCOLS users): it_tile says where the item's ascending rater list enters and
+    // leaves the tile, so every wave starts at its own entry.  (One wave per ITEM walked the most-rated item's 65 000 raters
+    // 64 at a time behind one dependent load each: that single wave took the whole millisecond of the kernel.)
     __shared__ unsigned long long cell[TPB / 64][64];
-    const int32_t item = (int32_t)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    constexpr int WPT = SELECT_TCOLS / 64;  // bitmap words per tile
+    const int n_tiles = tile_stride - 1;
+    const int64_t task = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int32_t item = (int32_t)(task / n_tiles), tile = (int32_t)(task - (int64_t)item * n_tiles);
     const int lane = threadIdx.x & 63;
-    const bool live = item < I;
-    // (every wave works on its own item and its own 64 LDS words: the phases below are ordered inside the wave only —
-    //  workgroup barriers made unrelated waves wait for each other's rater lists: 1.07 -> 0.6 ms)
+    if (item >= I) return;  // (the waves of a block only synchronise with themselves)
     auto wave_sync = [] {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
     unsigned long long* my = cell[threadIdx.x >> 6];
-    int64_t q = live ? i_ptr[item] : 0;
-    const int64_t qe = live ? i_ptr[item + 1] : 0;
-    unsigned long long* b = bits + (int64_t)(live ? item : 0) * words;
-    uint32_t* r = rank + (int64_t)(live ? item : 0) * words;
-    uint32_t run = 0;
-    for (int64_t w0 = 0; w0 < words; w0 += 64) {
+    const uint32_t* tb = it_tile + (int64_t)item * tile_stride + tile;
+    int64_t q = tb[0];
+    const int64_t qe = tb[1];
+    unsigned long long* b = bits + (int64_t)item * words;
+    uint32_t* r = rank + (int64_t)item * words;
+    uint32_t run = (uint32_t)(q - i_ptr[item]);  // raters of the item in earlier tiles
+    const int64_t w_end = min(words, (int64_t)(tile + 1) * WPT);
+    for (int64_t w0 = (int64_t)tile * WPT; w0 < w_end; w0 += 64) {
         my[lane] = 0;
         wave_sync();
         const int64_t v_end = (w0 + 64) * 64;  // users below v_end belong to this chunk or an earlier (finished) one
@@ -680,7 +698,7 @@ k_item_bits_rank(int32_t I, int64_t words, const int64_t* __restrict__ i_ptr, co
         const uint32_t c = (uint32_t)__popcll(word);
         const uint32_t incl = wave_incl_scan(c);
         const int64_t w = w0 + lane;
-        if (live && w < words) {
+        if (w < w_end) {
             b[w] = word;
             r[w] = run + incl - c;
         }
@@ -779,8 +797,9 @@ void prep_commit(Train& tr, PrepScratch& sc, hipStream_t st) {
             tr.ib_words = words;
             tr.item_bits.ensure((size_t)I * words);
             tr.item_rank.ensure((size_t)I * words);
-            k_item_bits_rank<<<nblocks((int64_t)I * 64), TPB, 0, st>>>(I, words, tr.i_ptr.p, tr.it_user.p,
-                                                                       reinterpret_cast<unsigned long long*>(tr.item_bits.p), tr.item_rank.p);
+            k_item_bits_rank<<<nblocks((int64_t)I * (tr.tile_stride - 1) * 64), TPB, 0, st>>>(
+                I, words, tr.i_ptr.p, tr.it_user.p, tr.it_tile.p, tr.tile_stride, reinterpret_cast<unsigned long long*>(tr.item_bits.p),
+                tr.item_rank.p);
             KN_HIP(hipGetLastError());
         } else {
             tr.ib_words = 0;
