@@ -150,8 +150,14 @@ __device__ __forceinline__ bool ranks_before(double sa, int32_t ia, double sb, i
 // over uItems.intersect(vItems).
 // Finally an LDS bitonic sort keeps the best kk; shortlists longer than the LDS tile are consumed
 // in chunks: [current best kk | next chunk] is sorted and cut to kk again (exact: total order).
-static constexpr int WBUF = 512;       // products per wave buffer
-static constexpr int UPRE_LDS = 1024;  // u's preprocessed ratings are kept in LDS up to this row length
+// LDS plan per shortlist tile.  TILE = 512 (k <= 384, the common case): 256-product wave buffers and u's ratings in LDS up to
+// 512 make a 49 KiB plan, and 85 VGPRs (launch bounds) let THREE workgroups share a CU instead of two — this kernel waits on
+// gathers 60 % of the time, so the extra waves pay: 13.5 -> 11.3 ms at the ml-25m shape.  Larger tiles keep the roomier plan.
+template <int TILE> struct RerankPlan {
+    static constexpr int WBUF = TILE <= 512 ? 256 : 512;       // products per wave buffer
+    static constexpr int UPRE_LDS = TILE <= 512 ? 512 : 1024;  // u's preprocessed ratings are kept in LDS up to this row length
+    static constexpr int WAVES_PER_EU = TILE <= 512 ? 6 : 4;
+};
 
 typedef const __attribute__((address_space(3))) double* lds_cf64;
 typedef __attribute__((address_space(3))) double* lds_f64;
@@ -199,7 +205,7 @@ typedef const __attribute__((address_space(3))) u32x2* lds_cu32x2;
 typedef __attribute__((address_space(3))) u32x2* lds_u32x2;
 
 // JAC: every hit contributes 1.0 (the fold then yields the exact number of common items)
-template <bool JAC, class PreP>
+template <bool JAC, int WBUF, class PreP>
 __device__ __forceinline__ double wave_sims(const Rows& R, lds_cu32x2 bp, PreP upre, int32_t nu, lds_f64 wb, lds_u32 meta,
                                             uint32_t my_b, uint32_t my_len, int n_c, int lane) {
     lds_u32x2 cpair = (lds_u32x2)meta;  // [64] (end of candidate j in the stream, entry of stream position 0 of j)
@@ -299,7 +305,7 @@ __device__ __forceinline__ double wave_sims(const Rows& R, lds_cu32x2 bp, PreP u
 }
 
 template <int TILE, bool JAC>
-__global__ void __launch_bounds__(TPB) k_rerank(Rows R, const int64_t* __restrict__ seq, int32_t n_rows,
+__global__ void __launch_bounds__(TPB, RerankPlan<TILE>::WAVES_PER_EU) k_rerank(Rows R, const int64_t* __restrict__ seq, int32_t n_rows,
                                                 const int32_t* __restrict__ row_user, int32_t cap,
                                                 const int32_t* __restrict__ cand_idx, const float* __restrict__ cand_approx,
                                                 const int32_t* __restrict__ cand_cnt, int32_t kk, int32_t kcap,
@@ -308,6 +314,7 @@ __global__ void __launch_bounds__(TPB) k_rerank(Rows R, const int64_t* __restric
                                                 double* __restrict__ stats, uint32_t* __restrict__ row_entries_out, int32_t words) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t part[TPB / 64];
+    constexpr int WBUF = RerankPlan<TILE>::WBUF, UPRE_LDS = RerankPlan<TILE>::UPRE_LDS;
     double* ssim = reinterpret_cast<double*>(smem);            // [TILE]
     double* upre = ssim + TILE;                                // [UPRE_LDS]
     double* wbuf = upre + UPRE_LDS;                            // [4][WBUF]
@@ -404,11 +411,11 @@ __global__ void __launch_bounds__(TPB) k_rerank(Rows R, const int64_t* __restric
             row_entries += len_v;  // algorithmic traffic of this kernel: the candidates' rows (12 B per entry)
             const bool small_v = (lane < n_c) && (len_v <= 4);
             if (JAC) {  // exact count of common items (no order involved, any row length), then :461
-                const double both = wave_sims<true>(R, (lds_cu32x2)bp, (lds_cf64)upre, nu, wb, meta, b_v, len_v, n_c, lane);
+                const double both = wave_sims<true, WBUF>(R, (lds_cu32x2)bp, (lds_cf64)upre, nu, wb, meta, b_v, len_v, n_c, lane);
                 s = both / (double)((int64_t)nu + (int64_t)len_v - (int64_t)both);
             } else if (nu > 4 && !__any(small_v)) {
-                s = pre_lds ? wave_sims<false>(R, (lds_cu32x2)bp, (lds_cf64)upre, nu, wb, meta, b_v, len_v, n_c, lane)
-                            : wave_sims<false>(R, (lds_cu32x2)bp, R.s_pre + ub, nu, wb, meta, b_v, len_v, n_c, lane);
+                s = pre_lds ? wave_sims<false, WBUF>(R, (lds_cu32x2)bp, (lds_cf64)upre, nu, wb, meta, b_v, len_v, n_c, lane)
+                            : wave_sims<false, WBUF>(R, (lds_cu32x2)bp, R.s_pre + ub, nu, wb, meta, b_v, len_v, n_c, lane);
             } else {
                 s = (lane < n_c) ? pair_sim(R, u, v, seq_u, seq[v]) : 0.0;
             }
@@ -506,6 +513,7 @@ static void launch_rerank_tile(const Rows& R, const Train& tr, NeighborTable& nt
                                int32_t cap, const int32_t* cand_idx, const float* cand_approx, const int32_t* cand_cnt,
                                const float* cand_eps, double* d_stats, uint32_t* d_row_entries, hipStream_t st) {
     const int32_t words = (int32_t)ceil_div(tr.I, 32);
+    constexpr int WBUF = RerankPlan<TILE>::WBUF, UPRE_LDS = RerankPlan<TILE>::UPRE_LDS;
     const size_t smem = (size_t)TILE * 8 + (size_t)UPRE_LDS * 8 + (size_t)(TPB / 64) * WBUF * 8 + (size_t)TILE * 4 +
                         (size_t)words * 8 + (size_t)(TPB / 64) * WMETA * 4;
     KN_REQUIRE(smem <= 160 * 1024 - 2048, KNNCF_E_UNSUPPORTED, "re-rank: item bitmap does not fit in LDS (too many items)");
@@ -529,10 +537,12 @@ void launch_rerank(const Train& tr, NeighborTable& nt, int32_t n_rows, const int
     Rows R{tr.u_ptr.p, tr.s_col.p, tr.s_t.p, tr.s_pre.p, (uint32_t)(tr.n * 4), (uint32_t)(tr.n * 8)};
     const float* apx = verify ? cand_approx : nullptr;
     if (tr.jaccard) {
-        if (nt.kcap <= 512) launch_rerank_tile<1024, true>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
+        if (nt.kcap <= 384) launch_rerank_tile<512, true>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
+        else if (nt.kcap <= 512) launch_rerank_tile<1024, true>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
         else launch_rerank_tile<2048, true>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
     } else {
-        if (nt.kcap <= 512) launch_rerank_tile<1024, false>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
+        if (nt.kcap <= 384) launch_rerank_tile<512, false>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
+        else if (nt.kcap <= 512) launch_rerank_tile<1024, false>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
         else launch_rerank_tile<2048, false>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
     }
 }
