@@ -302,7 +302,11 @@ def main():
             "data": "synthetic",
             "mae": mae,
             "config": {"workload": f"{split.name}: predict.kNN k={args.k}, {eng.num_users} users x {eng.num_items} items, "
-                                   f"{len(tr)} train / {n_test} test ratings", "parallelism": f"users block-partitioned x{world}"},
+                                   f"{len(tr)} train / {n_test} test ratings", "parallelism": f"users block-partitioned x{world}",
+                       # one step = knncf_fit + knncf_mae(PRED_KNN): what predict/kNN.scala:43-57 evaluates.  The per-item maps of the
+                       # baseline predictors (K4: itemsAvg, itemsAvgDev) are not on that path in the reference either (predictions.scala
+                       # :489-585 never calls them); the handle builds them on first use
+                       "step": "fit (K0-K3) + neighbourhoods (K5, K6) + predictions + MAE (K7, K8); K4 not on the kNN path"},
             "roofline": kernels[dominant],  # the dominant kernel of THIS run (by summed launch time)
             "roofline_all": kernels,
             "stage_ms_per_step": {k_: tm[k_] / steps for k_ in ("prep_ms", "densify_ms", "gemm_ms", "tail_ms", "select_ms", "rerank_ms", "predict_ms")},

@@ -88,7 +88,7 @@ typedef struct knncf_config {
 
 /* per-stage device timings of the last fit / neighbour build / predict, milliseconds */
 typedef struct knncf_timings {
-    double prep_ms;     /* K0-K4: id compaction, CSR/CSC, means, deviations, norms */
+    double prep_ms;     /* K0-K3 (and K4 when a call needed it): id compaction, CSR/CSC, means, deviations, norms */
     double densify_ms;  /* CSR -> 16-bit operand panels */
     double gemm_ms;     /* K5 similarity GEMM (all launches) */
     double tail_ms;     /* K5 sparse tail when run as its own pass (0: fused into select_ms) */
@@ -115,9 +115,16 @@ int knncf_create(const knncf_config* cfg, knncf_handle** out);
 void knncf_destroy(knncf_handle* h);
 const char* knncf_last_error(const knncf_handle* h);
 
-/* ---- fit: everything the reference's closures compute eagerly (K0-K4) ----- */
+/* ---- fit: everything the reference's kNN closures compute eagerly (K0-K3) -- */
 /* Rows are the collected Array[Rating] in FILE ORDER (the reference's summation
- * order and fallbacks depend on it).  Arrays are copied. */
+ * order and fallbacks depend on it).  Arrays are copied.
+ * K4 — the per-item maps of the baseline predictors (itemsAvg :134, itemsAvgDev
+ * :176-186, getItemsAvgDev :336-343) — is not part of the kNN closures
+ * (weightedSumDeviation :489-548, predictor :557-585 never evaluate them): the
+ * reference builds those maps when computeItemAvg / computePrediction / the Spark
+ * forms are constructed, and the handle builds them on the first call that reads
+ * them (knncf_item_avg*, KNNCF_PRED_ITEM_AVG / BASELINE / BASELINE_RDD, and
+ * PERSONALIZED with similarityOne), charged to prep_ms of that call. */
 int knncf_fit(knncf_handle* h, const int32_t* users, const int32_t* items,
               const double* ratings, int64_t n);
 int knncf_fit_device(knncf_handle* h, const int32_t* d_users, const int32_t* d_items,

@@ -553,6 +553,14 @@ void ensure_personalized_table(knncf_handle* h) {
     h->pt_ready = true;
 }
 
+// K4 on first use: computeItemAvg :141, computeItemAvgDev :193 and the Spark forms build their item maps when the predictor is
+// constructed; the kNN predictor (:489-585) never does, so knncf_fit leaves them out (prep.hip: prep_item_stats)
+void ensure_item_stats(knncf_handle* h) {
+    if (h->tr.item_stats_ready) return;
+    Stage s(h, &h->tm.prep_ms);
+    prep_item_stats(h->tr, h->prep, h->stream);
+}
+
 void run_predict(knncf_handle* h, int predictor, const int32_t* d_users, const int32_t* d_items,
                  const double* d_ratings, int64_t n, double* sum_abs_err, int64_t* count, double* d_pred_out) {
     require_fitted(h);
@@ -575,6 +583,7 @@ void run_predict(knncf_handle* h, int predictor, const int32_t* d_users, const i
         }
     }
     KN_REQUIRE(kind >= KNNCF_PRED_GLOBAL_AVG && kind <= KNNCF_PRED_KNN, KNNCF_E_INVALID, "unknown predictor");
+    if (kind == KNNCF_PRED_ITEM_AVG || kind == KNNCF_PRED_BASELINE || kind == KNNCF_PRED_BASELINE_RDD) ensure_item_stats(h);
     ensure_test_scratch(h, n);
     {
         Stage s(h, &h->tm.predict_ms);
@@ -917,6 +926,7 @@ int knncf_item_avg(knncf_handle* h, int32_t item, double* out) {
     return guarded(h, [&] {
         require_fitted(h);
         KN_REQUIRE(out, KNNCF_E_INVALID, "null out");
+        ensure_item_stats(h);
         int32_t d = dense_item(h, item);
         *out = d >= 0 ? fetch(h, h->tr.item_avg.p, d) : h->tr.global_avg;
     });
@@ -926,6 +936,7 @@ int knncf_item_avg_dev(knncf_handle* h, int32_t item, double* out) {
     return guarded(h, [&] {
         require_fitted(h);
         KN_REQUIRE(out, KNNCF_E_INVALID, "null out");
+        ensure_item_stats(h);
         int32_t d = dense_item(h, item);
         *out = d >= 0 ? fetch(h, h->tr.item_dev_hash.p, d) : 0.0;
     });
@@ -935,6 +946,7 @@ int knncf_item_avg_dev_rdd(knncf_handle* h, int32_t item, double* out) {
     return guarded(h, [&] {
         require_fitted(h);
         KN_REQUIRE(out, KNNCF_E_INVALID, "null out");
+        ensure_item_stats(h);
         int32_t d = dense_item(h, item);
         *out = d >= 0 ? fetch(h, h->tr.item_dev_file.p, d) : 0.0;
     });

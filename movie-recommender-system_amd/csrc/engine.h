@@ -59,11 +59,12 @@ struct Train {
     // fold orders (permutations of positions)
     DArr<uint32_t> perm_uf;  // (user, file order)            usersAvg :113
     DArr<uint32_t> perm_uh;  // (user, HashMap order, N4)      usersWeights :474
-    DArr<uint32_t> perm_if;  // (item, file order)            itemsAvg :134 / Spark :336-343
-    DArr<uint32_t> perm_ih;  // (item, HashMap order, N4)      itemsAvgDev :176-186
     DArr<int64_t> i_ptr;     // [I+1]
     DArr<double> user_avg, user_norm;  // [U]
+    // K4 (itemsAvg :134, itemsAvgDev :176-186, getItemsAvgDev :336-343): built on first use by prep_item_stats — the kNN
+    // path of the reference never evaluates them
     DArr<double> item_avg, item_dev_hash, item_dev_file;  // [I]
+    bool item_stats_ready = false;
     // item-major copies for the sparse tail of the hybrid similarity (fp32 is enough: it only filters)
     DArr<int32_t> it_user;   // [n] dense user of the q-th entry in (item, user ascending) order
     DArr<uint32_t> it_pack;  // [n] LDS cell of (user mod SELECT_TCOLS) << 17 | Q0.16 preprocessed rating: the sparse tail's 4-byte entry
@@ -100,17 +101,15 @@ struct PrepScratch {
     DArr<int32_t> idrange;  // [4] min / max raw user id, min / max raw item id
     DArr<double> dsum;      // small reduction scratch
     DArr<uint4> rec;        // [2 n] (preprocessed rating, deviation | user, file row) records: one 32-byte gather per entry
-    // side streams for the three independent item folds of prep_commit (created on first use)
-    hipStream_t aux[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     void release_all();
-    ~PrepScratch();
 };
 
 // K0 + K1 + owned part of K2/K3.  Throws Error on invalid data.
 void prep_fit(Train& tr, PrepScratch& sc, int32_t shard_rank, int32_t shard_count, hipStream_t st);
-// item-side folds (need every user's deviations): K4
+// item-major copies, rater bitmaps, popularity order (need every user's deviations: after the shards' exchange)
 void prep_commit(Train& tr, PrepScratch& sc, hipStream_t st);
+// K4: the per-item statistics of the baseline predictors (after prep_commit; sets tr.item_stats_ready)
+void prep_item_stats(Train& tr, PrepScratch& sc, hipStream_t st);
 
 // raw test ids -> dense (-1 = absent from train)
 void launch_dense_ids(const Train& tr, const int32_t* d_users, const int32_t* d_items, int64_t n,

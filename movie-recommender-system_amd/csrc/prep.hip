@@ -25,14 +25,6 @@ void PrepScratch::release_all() {
     k32_a.release(); k32_b.release(); du_row.release(); di_row.release(); perm_f.release(); rec.release();
 }
 
-PrepScratch::~PrepScratch() {
-    for (int i = 0; i < 3; ++i) {
-        if (aux[i]) (void)hipStreamDestroy(aux[i]);
-        if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
-    }
-    if (ev_fork) (void)hipEventDestroy(ev_fork);
-}
-
 // ---- K0: ids ---------------------------------------------------------------------------
 __global__ void k_row_keys(int64_t n, const int32_t* __restrict__ users, const int32_t* __restrict__ items,
                            uint32_t* __restrict__ ukey, uint32_t* __restrict__ ikey) {
@@ -167,6 +159,25 @@ __global__ void k_make_keys(int64_t n, int mode, const int32_t* __restrict__ du,
         default: k = ((uint64_t)(uint32_t)di[t] << 32) | tuple_trie_key(users[t], items[t]); break;
     }
     key[t] = k;
+}
+
+// sharded fits: keys over the owned slice [p0, p0 + m) of the canonical order — (user - lo, file row) with the position
+// as the value, then (user - lo, trie key of the (user, item) tuple) along the first sort's result
+__global__ void k_slice_file_keys(int64_t p0, int64_t m, int32_t lo, const int32_t* __restrict__ s_user, const uint32_t* __restrict__ s_t,
+                                  int tbits, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const int64_t p = p0 + j;
+    key[j] = ((uint64_t)(uint32_t)(s_user[p] - lo) << tbits) | s_t[p];
+    val[j] = (uint32_t)p;
+}
+__global__ void k_slice_hash_keys(int64_t m, int32_t lo, const uint32_t* __restrict__ pos, const int32_t* __restrict__ s_user,
+                                  const uint32_t* __restrict__ s_t, const int32_t* __restrict__ users, const int32_t* __restrict__ items,
+                                  uint64_t* __restrict__ key) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const uint32_t p = pos[j], t = s_t[p];
+    key[j] = ((uint64_t)(uint32_t)(s_user[p] - lo) << 32) | tuple_trie_key(users[t], items[t]);
 }
 
 // 32-bit keys for the two plain fold orders (a third less sort traffic than 64-bit keys)
@@ -536,24 +547,52 @@ void prep_fit(Train& tr, PrepScratch& sc, int32_t shard_rank, int32_t shard_coun
     k_invert<<<nblocks(n), TPB, 0, st>>>(n, tr.s_t.p, sc.perm_f.p);
     KN_HIP(hipGetLastError());
 
+    // owned block of users (SURVEY 8e): ascending dense index, ceil(U / shards) each
+    const int32_t per = (int32_t)ceil_div(U, shard_count);
+    tr.own_lo = std::min<int64_t>((int64_t)per * shard_rank, U);
+    tr.own_hi = std::min<int64_t>((int64_t)per * (shard_rank + 1), U);
+    const int32_t lo = tr.own_lo, hi = tr.own_hi;
+    int64_t p0 = 0, p1 = n;  // the owned users' positions in the canonical order
+    if (shard_count > 1) {
+        int64_t hp[2];
+        KN_HIP(hipMemcpyAsync(&hp[0], tr.u_ptr.p + lo, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        KN_HIP(hipMemcpyAsync(&hp[1], tr.u_ptr.p + hi, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        KN_HIP(hipStreamSynchronize(st));
+        p0 = hp[0];
+        p1 = hp[1];
+    }
+
     // fold orders: stable sorts of the file-order sequence of positions
-    tr.perm_uf.alloc(n); tr.perm_if.alloc(n);
-    k_copy_keys_u32<<<nblocks(n), TPB, 0, st>>>(n, sc.du_row.p, sc.k32_a.p);
-    sort_pairs_u32_u32(sc.sort, sc.k32_a.p, sc.k32_b.p, sc.perm_f.p, tr.perm_uf.p, n, ubits, st);
-    k_copy_keys_u32<<<nblocks(n), TPB, 0, st>>>(n, sc.di_row.p, sc.k32_a.p);
-    sort_pairs_u32_u32(sc.sort, sc.k32_a.p, sc.k32_b.p, sc.perm_f.p, tr.perm_if.p, n, ibits, st);
-    k_segment_ptr_u32<<<nblocks((int64_t)I + 1), TPB, 0, st>>>(n, sc.k32_b.p, tr.I, tr.i_ptr.p);
+    // (the item-side fold orders belong to K4, which only the baseline predictors use: prep_item_stats)
+    tr.perm_uf.alloc(n);
+    if (shard_count == 1) {
+        k_copy_keys_u32<<<nblocks(n), TPB, 0, st>>>(n, sc.du_row.p, sc.k32_a.p);
+        sort_pairs_u32_u32(sc.sort, sc.k32_a.p, sc.k32_b.p, sc.perm_f.p, tr.perm_uf.p, n, ubits, st);
+    } else if (p1 > p0) {
+        // A shard folds its own users only (K2, K3 below), so it orders only their positions: the slice [p0, p1) of the
+        // canonical order by (user, file row) — the same segments the whole-file sort yields, 1/shards of the work.
+        const int tbits = bits_for((uint64_t)n);
+        k_slice_file_keys<<<nblocks(p1 - p0), TPB, 0, st>>>(p0, p1 - p0, lo, tr.s_user.p, tr.s_t.p, tbits, sc.k64_a.p, sc.v32_a.p);
+        KN_HIP(hipGetLastError());
+        sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.v32_a.p, tr.perm_uf.p + p0, p1 - p0, tbits + bits_for((uint64_t)(hi - lo)), st);
+    }
     KN_HIP(hipGetLastError());
     if (n > 4) {  // a Map of <= 4 entries (Map1..Map4) iterates in insertion = file order (N4)
-        tr.perm_uh.alloc(n); tr.perm_ih.alloc(n);
-        k_make_keys<<<nblocks(n), TPB, 0, st>>>(n, 2, sc.du_row.p, sc.di_row.p, tr.user_raw.p, tr.item_raw.p, sc.k64_a.p, 32);
-        sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.perm_f.p, tr.perm_uh.p, n, 32 + ubits, st);
-        k_make_keys<<<nblocks(n), TPB, 0, st>>>(n, 4, sc.du_row.p, sc.di_row.p, tr.user_raw.p, tr.item_raw.p, sc.k64_a.p, 32);
-        sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.perm_f.p, tr.perm_ih.p, n, 32 + ibits, st);
+        tr.perm_uh.alloc(n);
+        if (shard_count == 1) {
+            k_make_keys<<<nblocks(n), TPB, 0, st>>>(n, 2, sc.du_row.p, sc.di_row.p, tr.user_raw.p, tr.item_raw.p, sc.k64_a.p, 32);
+            sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.perm_f.p, tr.perm_uh.p, n, 32 + ubits, st);
+        } else if (p1 > p0) {  // the slice in (user, file row) order, stably re-sorted by (user, trie key)
+            k_slice_hash_keys<<<nblocks(p1 - p0), TPB, 0, st>>>(p1 - p0, lo, tr.perm_uf.p + p0, tr.s_user.p, tr.s_t.p, tr.user_raw.p,
+                                                               tr.item_raw.p, sc.k64_a.p);
+            KN_HIP(hipGetLastError());
+            sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, tr.perm_uf.p + p0, tr.perm_uh.p + p0, p1 - p0,
+                               32 + bits_for((uint64_t)(hi - lo)), st);
+        }
     } else {
         tr.perm_uh.release();
-        tr.perm_ih.release();
     }
+    tr.item_stats_ready = false;
 
     // K1: average :94 — left fold over the file; exact in any order for dyadic ratings
     k_check_dyadic<<<nblocks(n), TPB, 0, st>>>(n, tr.rating.p, sc.status.p);
@@ -576,10 +615,6 @@ void prep_fit(Train& tr, PrepScratch& sc, int32_t shard_rank, int32_t shard_coun
     KN_HIP(hipStreamSynchronize(st));
     tr.global_avg = total / (double)n;
 
-    // owned block of users (SURVEY 8e): ascending dense index, ceil(U / shards) each
-    int32_t per = (int32_t)ceil_div(U, shard_count);
-    tr.own_lo = std::min<int64_t>((int64_t)per * shard_rank, U);
-    tr.own_hi = std::min<int64_t>((int64_t)per * (shard_rank + 1), U);
     tr.user_avg.alloc(U); tr.user_norm.alloc(U);
     if (shard_count > 1) {  // the host all-gathers the other shards' segments in place
         KN_HIP(hipMemsetAsync(tr.user_avg.p, 0, U * sizeof(double), st));
@@ -587,13 +622,7 @@ void prep_fit(Train& tr, PrepScratch& sc, int32_t shard_rank, int32_t shard_coun
         KN_HIP(hipMemsetAsync(tr.s_dev.p, 0, n * sizeof(double), st));
         KN_HIP(hipMemsetAsync(tr.s_pre.p, 0, n * sizeof(double), st));
     }
-    const int32_t lo = tr.own_lo, hi = tr.own_hi;
     if (hi > lo) {
-        int64_t hp[2];
-        KN_HIP(hipMemcpyAsync(&hp[0], tr.u_ptr.p + lo, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-        KN_HIP(hipMemcpyAsync(&hp[1], tr.u_ptr.p + hi, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-        KN_HIP(hipStreamSynchronize(st));
-        const int64_t p0 = hp[0], p1 = hp[1];
         // K2: usersAvg :113 (groupBy keeps file order; mean = reduce(_+_) / length)
         fold<false>(tr.u_ptr.p, lo, hi, tr.perm_uf.p, tr.s_rating.p, tr.user_norm.p, st);
         k_divide_by_count<<<nblocks(hi - lo), TPB, 0, st>>>(tr.u_ptr.p, lo, hi, tr.user_norm.p, tr.user_avg.p);
@@ -723,10 +752,10 @@ __global__ void k_item_tiles(int32_t I, int32_t stride, const int64_t* __restric
     it_tile[g] = (uint32_t)lo;
 }
 
-__global__ void k_col_keys(int64_t n, const int32_t* __restrict__ s_col, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
+__global__ void k_col_keys(int64_t n, const int32_t* __restrict__ s_col, uint32_t* __restrict__ key, uint32_t* __restrict__ val) {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    key[p] = (uint64_t)(uint32_t)s_col[p];
+    key[p] = (uint32_t)s_col[p];
     val[p] = (uint32_t)p;
 }
 
@@ -741,45 +770,16 @@ __global__ void k_pop_keys(int32_t I, const int64_t* __restrict__ i_ptr, uint64_
 void prep_commit(Train& tr, PrepScratch& sc, hipStream_t st) {
     const int64_t n = tr.n;
     const int32_t I = tr.I;
-    // Three independent ordered folds over the item segments.  Each is bound by the serial fp64 chain of its longest
-    // segment (an item with 0.4 % of all ratings), not by bandwidth: they run side by side on three streams, forked
-    // here and joined at the end, under the item-major copies and the bitmaps that this stream builds meanwhile.  (HIP
-    // maps streams of one priority onto few hardware queues — two of three equal-priority streams shared one and ran
-    // back to back — so the three streams get the three priority levels.)
-    tr.item_avg.alloc(I); tr.item_dev_hash.alloc(I); tr.item_dev_file.alloc(I);
-    const size_t slab = (size_t)I + 2;
-    sc.dsum.ensure(3 * slab);
-    if (!sc.aux[0]) {
-        int prio_least = 0, prio_greatest = 0;
-        KN_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-        const int prio[3] = {prio_greatest, (prio_least + prio_greatest) / 2, prio_least};
-        for (int i = 0; i < 3; ++i) {
-            KN_HIP(hipStreamCreateWithPriority(&sc.aux[i], hipStreamNonBlocking, prio[i]));
-            KN_HIP(hipEventCreateWithFlags(&sc.ev_join[i], hipEventDisableTiming));
-        }
-        KN_HIP(hipEventCreateWithFlags(&sc.ev_fork, hipEventDisableTiming));
-    }
-    KN_HIP(hipEventRecord(sc.ev_fork, st));
-    for (int i = 0; i < 3; ++i) KN_HIP(hipStreamWaitEvent(sc.aux[i], sc.ev_fork, 0));
-    // itemsAvg :134
-    fold<false>(tr.i_ptr.p, 0, I, tr.perm_if.p, tr.s_rating.p, sc.dsum.p, sc.aux[0], 16);
-    k_divide_by_count<<<nblocks(I), TPB, 0, sc.aux[0]>>>(tr.i_ptr.p, 0, I, sc.dsum.p, tr.item_avg.p);
-    // getItemsAvgDev :336-343 (reduceByKey, modelled in file order)
-    fold<false>(tr.i_ptr.p, 0, I, tr.perm_if.p, tr.s_dev.p, sc.dsum.p + slab, sc.aux[1], 16);
-    k_divide_by_count<<<nblocks(I), TPB, 0, sc.aux[1]>>>(tr.i_ptr.p, 0, I, sc.dsum.p + slab, tr.item_dev_file.p);
-    // itemsAvgDev :176-186 (foldLeft over the HashMap: trie order of the (user,item) hashes)
-    fold<false>(tr.i_ptr.p, 0, I, n > 4 ? tr.perm_ih.p : tr.perm_if.p, tr.s_dev.p, sc.dsum.p + 2 * slab, sc.aux[2], 16);
-    k_divide_by_count<<<nblocks(I), TPB, 0, sc.aux[2]>>>(tr.i_ptr.p, 0, I, sc.dsum.p + 2 * slab, tr.item_dev_hash.p);
-    for (int i = 0; i < 3; ++i) KN_HIP(hipEventRecord(sc.ev_join[i], sc.aux[i]));
-    KN_HIP(hipGetLastError());
     // item-major copies + popularity order (hybrid similarity: dense head / sparse tail)
     // (item, user ascending) order: a stable sort of the user-major positions by item
     tr.it_user.alloc(n); tr.it_pack.alloc(n); tr.it_dev.alloc(n); tr.it_t.alloc(n); tr.pop_item.alloc(I);
     sc.k64_a.ensure(std::max<int64_t>(n, I)); sc.k64_b.ensure(std::max<int64_t>(n, I));
     sc.v32_a.ensure(std::max<int64_t>(n, I)); sc.v32_b.ensure(n);
-    k_col_keys<<<nblocks(n), TPB, 0, st>>>(n, tr.s_col.p, sc.k64_a.p, sc.v32_a.p);
+    sc.k32_a.ensure(n); sc.k32_b.ensure(n);
+    k_col_keys<<<nblocks(n), TPB, 0, st>>>(n, tr.s_col.p, sc.k32_a.p, sc.v32_a.p);
     KN_HIP(hipGetLastError());
-    sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.v32_a.p, sc.v32_b.p, n, bits_for(I), st);
+    sort_pairs_u32_u32(sc.sort, sc.k32_a.p, sc.k32_b.p, sc.v32_a.p, sc.v32_b.p, n, bits_for(I), st);
+    k_segment_ptr_u32<<<nblocks((int64_t)I + 1), TPB, 0, st>>>(n, sc.k32_b.p, I, tr.i_ptr.p);
     sc.rec.ensure(2 * (size_t)n);
     k_pack_records<<<nblocks(n), TPB, 0, st>>>(n, tr.s_user.p, tr.s_pre.p, tr.s_dev.p, tr.s_t.p, sc.rec.p);
     k_item_major<<<nblocks(n), TPB, 0, st>>>(n, sc.v32_b.p, sc.rec.p, tr.it_user.p, tr.it_pack.p, tr.it_dev.p, tr.it_t.p, tr.jaccard ? 1 : 0);
@@ -815,8 +815,59 @@ void prep_commit(Train& tr, PrepScratch& sc, hipStream_t st) {
         tr.pop_count.resize(I);
         for (int32_t i = 0; i < I; ++i) tr.pop_count[i] = (int64_t)~hk[i];
     }
-    for (int i = 0; i < 3; ++i) KN_HIP(hipStreamWaitEvent(st, sc.ev_join[i], 0));
     KN_HIP(hipGetLastError());
+}
+
+// K4, the per-item statistics of the baseline predictors — itemsAvg :134, itemsAvgDev :176-186 (foldLeft over the HashMap: trie
+// order of the (user, item) tuple hashes), getItemsAvgDev :336-343 (reduceByKey, modelled in file order).  The reference's kNN
+// closures (weightedSumDeviation :489-548, predictor :557-585) never evaluate them, and neither does knncf_fit: the first
+// predictor or query that reads them calls this (api.cpp: ensure_item_stats).  Ordered fp64 folds over each item's ratings;
+// the two fold orders are stable sorts of the positions.
+__global__ void k_item_file_keys(int64_t n, const int32_t* __restrict__ s_col, const uint32_t* __restrict__ s_t, int tbits,
+                                 uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    key[p] = ((uint64_t)(uint32_t)s_col[p] << tbits) | s_t[p];
+    val[p] = (uint32_t)p;
+}
+__global__ void k_item_hash_keys(int64_t n, const uint32_t* __restrict__ pos, const int32_t* __restrict__ s_col,
+                                 const uint32_t* __restrict__ s_t, const int32_t* __restrict__ users, const int32_t* __restrict__ items,
+                                 uint64_t* __restrict__ key) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t p = pos[j], t = s_t[p];
+    key[j] = ((uint64_t)(uint32_t)s_col[p] << 32) | tuple_trie_key(users[t], items[t]);
+}
+
+void prep_item_stats(Train& tr, PrepScratch& sc, hipStream_t st) {
+    const int64_t n = tr.n;
+    const int32_t I = tr.I;
+    tr.item_avg.alloc(I); tr.item_dev_hash.alloc(I); tr.item_dev_file.alloc(I);
+    sc.k64_a.ensure(std::max<int64_t>(n, I)); sc.k64_b.ensure(std::max<int64_t>(n, I));
+    sc.v32_a.ensure(std::max<int64_t>(n, I)); sc.v32_b.ensure(n); sc.k32_a.ensure(n);
+    sc.dsum.ensure((size_t)I + 2);
+    const int tbits = bits_for((uint64_t)n), ibits = bits_for((uint64_t)I);
+    uint32_t* perm_if = sc.v32_b.p;  // (item, file row)
+    uint32_t* perm_ih = sc.k32_a.p;  // (item, trie key of the tuple; ties in file order)
+    k_item_file_keys<<<nblocks(n), TPB, 0, st>>>(n, tr.s_col.p, tr.s_t.p, tbits, sc.k64_a.p, sc.v32_a.p);
+    KN_HIP(hipGetLastError());
+    sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.v32_a.p, perm_if, n, tbits + ibits, st);
+    if (n > 4) {  // a Map of <= 4 entries (Map1..Map4) iterates in insertion = file order (N4)
+        k_item_hash_keys<<<nblocks(n), TPB, 0, st>>>(n, perm_if, tr.s_col.p, tr.s_t.p, tr.user_raw.p, tr.item_raw.p, sc.k64_a.p);
+        KN_HIP(hipGetLastError());
+        sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, perm_if, perm_ih, n, 32 + ibits, st);
+    } else {
+        perm_ih = perm_if;
+    }
+    // (each fold is bound by the serial fp64 chain of its longest segment; 16 segments per block spread the long ones)
+    fold<false>(tr.i_ptr.p, 0, I, perm_if, tr.s_rating.p, sc.dsum.p, st, 16);
+    k_divide_by_count<<<nblocks(I), TPB, 0, st>>>(tr.i_ptr.p, 0, I, sc.dsum.p, tr.item_avg.p);
+    fold<false>(tr.i_ptr.p, 0, I, perm_if, tr.s_dev.p, sc.dsum.p, st, 16);
+    k_divide_by_count<<<nblocks(I), TPB, 0, st>>>(tr.i_ptr.p, 0, I, sc.dsum.p, tr.item_dev_file.p);
+    fold<false>(tr.i_ptr.p, 0, I, perm_ih, tr.s_dev.p, sc.dsum.p, st, 16);
+    k_divide_by_count<<<nblocks(I), TPB, 0, st>>>(tr.i_ptr.p, 0, I, sc.dsum.p, tr.item_dev_hash.p);
+    KN_HIP(hipGetLastError());
+    tr.item_stats_ready = true;
 }
 
 }  // namespace knncf

@@ -70,6 +70,8 @@ for seed in range(first, first + count):
         ok = False
         print("seed", seed, "exception", repr(ex))
     done += 1
+    if done % 20 == 0:
+        print(f"... {done} cases, {bad} mismatches so far", flush=True)  # (a silent GPU command is taken to be hung)
     if not ok:
         bad += 1
         print("MISMATCH seed", seed, dict(n_users=n_users, n_items=n_items, n_ratings=n_ratings, k=k, flags=flags, head=head, sim=sim,

@@ -542,38 +542,42 @@ def test_ml25m_shape_eight_shards_on_one_gpu(kn, pkg, full25m):
     dev = tr[0].device
     world = 8
     engines = [kn.Engine(k=300, shard_rank=r, shard_count=world) for r in range(world)]
-    views = []
+    # two passes over the whole protocol: the first one allocates every buffer (hipMalloc stalls of up to seconds were seen
+    # in it), the second is the steady state the timings are taken from — like bench.py's warm-up steps
+    for rehearsal in range(2):
+        views = []
+        for e in engines:
+            e.reset_timings()
+            e.fit_device(*tr)
+            views.append(sharded.DeviceEngineAdapter(e, dev).shard_tensors())
+        for r in range(1, world):
+            assert views[r - 1]["user_range"][1] == views[r]["user_range"][0]
+        assert views[0]["user_range"][0] == 0 and views[-1]["user_range"][1] == engines[0].num_users
+        for me in range(world):
+            for other in range(world):
+                if other == me:
+                    continue
+                ulo, uhi = views[other]["user_range"]
+                nlo, nhi = views[other]["nnz_range"]
+                for key, lo, hi in (("user_avg", ulo, uhi), ("user_norm", ulo, uhi), ("dev", nlo, nhi), ("pre", nlo, nhi)):
+                    views[me][key][lo:hi] = views[other][key][lo:hi]
+        torch.cuda.synchronize()
+        total, count = 0.0, 0
+        preds = torch.full((len(d.test.users),), float("nan"), dtype=torch.float64, device=dev)
+        report = []
+        for r, e in enumerate(engines):
+            e.shard_commit()
+            s, c = e.mae_device(kn.PRED_KNN, *te, pred_out=preds)
+            total += s
+            count += c
+            t = e.timings()
+            assert t["fallback_rows"] == 0
+            stage = {k_: t[k_] for k_ in ("prep_ms", "densify_ms", "gemm_ms", "select_ms", "rerank_ms", "predict_ms")}
+            ulo, uhi = views[r]["user_range"]
+            nlo, nhi = views[r]["nnz_range"]
+            report.append({"rank": r, "users": uhi - ulo, "train_ratings": nhi - nlo, "test_rows": c, "stage_ms": stage,
+                           "step_ms": sum(stage.values())})
     for e in engines:
-        e.reset_timings()
-        e.fit_device(*tr)
-        views.append(sharded.DeviceEngineAdapter(e, dev).shard_tensors())
-    for r in range(1, world):
-        assert views[r - 1]["user_range"][1] == views[r]["user_range"][0]
-    assert views[0]["user_range"][0] == 0 and views[-1]["user_range"][1] == engines[0].num_users
-    for me in range(world):
-        for other in range(world):
-            if other == me:
-                continue
-            ulo, uhi = views[other]["user_range"]
-            nlo, nhi = views[other]["nnz_range"]
-            for key, lo, hi in (("user_avg", ulo, uhi), ("user_norm", ulo, uhi), ("dev", nlo, nhi), ("pre", nlo, nhi)):
-                views[me][key][lo:hi] = views[other][key][lo:hi]
-    torch.cuda.synchronize()
-    total, count = 0.0, 0
-    preds = torch.full((len(d.test.users),), float("nan"), dtype=torch.float64, device=dev)
-    report = []
-    for r, e in enumerate(engines):
-        e.shard_commit()
-        s, c = e.mae_device(kn.PRED_KNN, *te, pred_out=preds)
-        total += s
-        count += c
-        t = e.timings()
-        assert t["fallback_rows"] == 0
-        stage = {k_: t[k_] for k_ in ("prep_ms", "densify_ms", "gemm_ms", "select_ms", "rerank_ms", "predict_ms")}
-        ulo, uhi = views[r]["user_range"]
-        nlo, nhi = views[r]["nnz_range"]
-        report.append({"rank": r, "users": uhi - ulo, "train_ratings": nhi - nlo, "test_rows": c, "stage_ms": stage,
-                       "step_ms": sum(stage.values())})
         e.close()
     assert count == f["count"] == len(d.test.users)
     got = preds.cpu().numpy()
@@ -582,7 +586,7 @@ def test_ml25m_shape_eight_shards_on_one_gpu(kn, pkg, full25m):
     single = {k_: f["timings"][k_] for k_ in ("prep_ms", "densify_ms", "gemm_ms", "select_ms", "rerank_ms", "predict_ms")}
     os.makedirs("gpurun_out", exist_ok=True)
     with open(os.path.join("gpurun_out", "shard8_timings.json"), "w") as fh:
-        json.dump({"workload": "syn-25m k=300, 8 shards rehearsed on one MI355X (one after the other)",
+        json.dump({"workload": "syn-25m k=300, 8 shards rehearsed on one MI355X (one after the other; second pass = steady state)",
                    "single_engine_stage_ms_with_verify_flag": single, "single_engine_step_ms": sum(single.values()),
                    "shards": report, "projected_step_ms_8gpu_excl_exchange": max(x["step_ms"] for x in report)}, fh, indent=1)
 
