@@ -13,6 +13,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "engine.h"
 
 namespace knncf {
@@ -208,6 +210,7 @@ typedef __attribute__((address_space(3))) u32x2* lds_u32x2;
 template <bool JAC, int WBUF, class PreP>
 __device__ __forceinline__ double wave_sims(const Rows& R, lds_cu32x2 bp, PreP upre, int32_t nu, lds_f64 wb, lds_u32 meta,
                                             uint32_t my_b, uint32_t my_len, int n_c, int lane) {
+    constexpr bool PRE_IN_LDS = !std::is_same<PreP, const double*>::value;
     lds_u32x2 cpair = (lds_u32x2)meta;  // [64] (end of candidate j in the stream, entry of stream position 0 of j)
     lds_u32 cofs = meta + 128;          // [65] first product of candidate j in the product buffer
     const uint32_t incl = wave_incl_scan(my_len);
@@ -276,6 +279,7 @@ __device__ __forceinline__ double wave_sims(const Rows& R, lds_cu32x2 bp, PreP u
                 if (off + 64 * GRP > WBUF) fold();
                 u32x2 wp[GRP];
                 unsigned long long mask[GRP];
+                bool hits[GRP];
                 double prod[GRP];
 #pragma unroll
                 for (int k = 0; k < GRP; ++k) wp[k] = bp[pc[g + k] >> 5];  // (an absent entry reads word 0: harmless)
@@ -284,14 +288,17 @@ __device__ __forceinline__ double wave_sims(const Rows& R, lds_cu32x2 bp, PreP u
                     const uint32_t c = pc[g + k];
                     const bool hit = ((wp[k].x >> (c & 31u)) & pfl[g + k] & 1u) != 0u;
                     mask[k] = __ballot(hit);
-                    // position of item c in u's row (for a miss: some position of the row, its value is not used)
-                    const int32_t idx = min((int32_t)(wp[k].y + __popc(wp[k].x & ((1u << (c & 31u)) - 1u))), nu - 1);
+                    hits[k] = hit;
+                    // position of item c in u's row (for a miss: some position of the row, its value is not used; at most nu,
+                    // which an LDS copy of the row may read — the next LDS array — but a global row must not)
+                    int32_t idx = (int32_t)(wp[k].y + __popc(wp[k].x & ((1u << (c & 31u)) - 1u)));
+                    if (!PRE_IN_LDS) idx = min(idx, nu - 1);
                     prod[k] = JAC ? 1.0 : upre[idx] * __hiloint2double((int)py[g + k].y, (int)py[g + k].x);
                 }
 #pragma unroll
                 for (int k = 0; k < GRP; ++k) {
                     const uint32_t pos = off + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask[k], 0u));
-                    if ((mask[k] >> lane) & 1ull) wb[pos] = prod[k];
+                    if (hits[k]) wb[pos] = prod[k];
                     if (pfl[g + k] & 2u) cofs[pfl[g + k] >> 8] = pos;  // this candidate's products start here
                     off += (uint32_t)__popcll(mask[k]);
                 }
