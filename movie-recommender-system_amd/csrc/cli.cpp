@@ -63,10 +63,20 @@ bool parse_int(const std::string& s, int32_t* out) {
 
 // load shared/predictions.scala:35-49 through the library's multithreaded parser (csrc/loader.cpp): header and
 // non-numeric-first-column lines are dropped silently, a kept line with a bad column 1 or 2 fails loudly
+// --cache-dir DIR: the parse result is kept as DIR/<file name>.knncf (knncf_load_file_cached) and read back while the file
+// is unchanged
+std::string g_cache_dir;
+
 bool load_ratings(const std::string& path, const std::string& sep, Ratings* out, std::string* err) {
     knncf_ratings r;
     char msg[512] = {0};
-    if (knncf_load_file(path.c_str(), sep.c_str(), 0, &r, msg, (int)sizeof msg) != KNNCF_OK) {
+    std::string cache;
+    if (!g_cache_dir.empty()) {
+        const size_t slash = path.find_last_of('/');
+        cache = g_cache_dir + "/" + (slash == std::string::npos ? path : path.substr(slash + 1)) + ".knncf";
+    }
+    int hit = 0;
+    if (knncf_load_file_cached(path.c_str(), sep.c_str(), 0, cache.empty() ? nullptr : cache.c_str(), &r, &hit, msg, (int)sizeof msg) != KNNCF_OK) {
         *err = msg;
         return false;
     }
@@ -383,6 +393,7 @@ int usage() {
     fprintf(stderr,
             "usage: knncf {baseline|personalized|knn|distributed-baseline|load-check} --train FILE --test FILE\n"
             "             [--separator SEP] [--num_measurements N] [--json FILE] [--master M] [--k K] [--device D]\n"
+            "             [--cache-dir DIR]   (binary cache of the parsed files, read back while they are unchanged)\n"
             "       knncf recommend --data FILE --personal FILE [--separator SEP] [--json FILE] [--any-size]\n");
     return 2;
 }
@@ -410,6 +421,7 @@ int main(int argc, char** argv) {
         else if (k == "--data") a.data = need("--data");
         else if (k == "--personal") a.personal = need("--personal");
         else if (k == "--any-size") a.any_size = true;
+        else if (k == "--cache-dir") g_cache_dir = need("--cache-dir");
         else { fprintf(stderr, "[knncf] unknown option %s\n", k.c_str()); return usage(); }
     }
     if (a.separator == "\\t") a.separator = "\t";

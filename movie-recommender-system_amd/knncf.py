@@ -38,13 +38,21 @@ class Ratings(C.Structure):
                 ("ratings", C.POINTER(C.c_double))]
 
 
-def load_file(path, separator="\t", threads=0):
+def load_file(path, separator="\t", threads=0, cache=None, info=None):
     """`load` shared/predictions.scala:35-49 through the library's multithreaded parser: (users, items, ratings) in
-    file order.  No GPU needed."""
+    file order.  No GPU needed.  cache: path of the binary cache (knncf_load_file_cached): read when it matches the
+    file as it is now, (re)written otherwise; info (a dict) then receives {"from_cache": bool}."""
     L = load_library()
     r = Ratings()
     err = C.create_string_buffer(512)
-    st = L.knncf_load_file(os.fsencode(path), separator.encode(), threads, C.byref(r), err, len(err))
+    if cache is None:
+        st = L.knncf_load_file(os.fsencode(path), separator.encode(), threads, C.byref(r), err, len(err))
+    else:
+        hit = C.c_int(0)
+        st = L.knncf_load_file_cached(os.fsencode(path), separator.encode(), threads, os.fsencode(cache), C.byref(r),
+                                      C.byref(hit), err, len(err))
+        if info is not None:
+            info["from_cache"] = bool(hit.value)
     if st != 0:
         raise KnncfError(st, err.value.decode(errors="replace"))
     try:
@@ -110,7 +118,7 @@ EXPORTS = [
     "knncf_knn_similarity", "knncf_neighbors", "knncf_neighbors_batch", "knncf_predict", "knncf_recommend", "knncf_predict_batch",
     "knncf_predict_batch_device", "knncf_mae", "knncf_mae_device", "knncf_shard_view_get",
     "knncf_shard_commit", "knncf_get_timings", "knncf_reset_timings", "knncf_reset_neighbors",
-    "knncf_set_k", "knncf_load_file", "knncf_free_ratings", "knncf_load_personal", "knncf_free_personal", "knncf_neighbors_save", "knncf_neighbors_load",
+    "knncf_set_k", "knncf_load_file", "knncf_load_file_cached", "knncf_free_ratings", "knncf_load_personal", "knncf_free_personal", "knncf_neighbors_save", "knncf_neighbors_load",
 ]
 
 
@@ -186,6 +194,8 @@ def load_library():
     L.knncf_reset_neighbors.argtypes = [C.c_void_p]
     L.knncf_set_k.argtypes = [C.c_void_p, C.c_int32]
     L.knncf_load_file.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(Ratings), C.c_char_p, C.c_int]
+    L.knncf_load_file_cached.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.POINTER(Ratings), C.POINTER(C.c_int),
+                                         C.c_char_p, C.c_int]
     L.knncf_free_ratings.argtypes = [C.POINTER(Ratings)]
     L.knncf_free_ratings.restype = None
     L.knncf_load_personal.argtypes = [C.c_char_p, C.c_int32, C.POINTER(Personal), C.c_char_p, C.c_int]

@@ -28,6 +28,13 @@ def test_loader_quirks(cli, tmp_path):
     out = subprocess.run([cli, "load-check", "--train", str(p), "--separator", ","], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     assert "rows: 3" in out.stdout and "first: 1 10 4.5" in out.stdout and "last: 3 12 5" in out.stdout
+    # --cache-dir: the second run reads the binary cache of the parse and prints the same rows
+    cdir = tmp_path / "cache"
+    cdir.mkdir()
+    for _ in range(2):
+        again = subprocess.run([cli, "load-check", "--train", str(p), "--separator", ",", "--cache-dir", str(cdir)], capture_output=True, text=True)
+        assert again.returncode == 0 and again.stdout == out.stdout
+    assert (cdir / "r.csv.knncf").exists()
     bad = tmp_path / "bad.tsv"
     bad.write_text("1\t2\n")  # cols(2) out of bounds in the reference -> exception; here: loud failure
     out = subprocess.run([cli, "load-check", "--train", str(bad)], capture_output=True, text=True)

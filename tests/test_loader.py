@@ -74,6 +74,53 @@ def test_loader_is_order_preserving_across_threads(kn, synth, tmp_path, threads)
         np.testing.assert_array_equal(r[rep * n:(rep + 1) * n], d.train.ratings)
 
 
+def test_ratings_cache_round_trip_and_invalidation(kn, synth, tmp_path):
+    """SURVEY 8f.2, the on-disk cache: the second load of an unchanged file comes from the binary cache and is the same
+    triples in the same (file) order; a changed file, another separator, a truncated or a corrupted cache are not used."""
+    d = synth.syn_scaled(300, 200, 12_000, seed=5, shuffle=True)
+    src = tmp_path / "u.data"
+    with open(src, "w") as fh:
+        fh.write("userId\titemId\trating\n")
+        for u, i, r in zip(d.train.users, d.train.items, d.train.ratings):
+            fh.write(f"{u}\t{i}\t{r}\n")
+    cache = tmp_path / "u.data.knncf"
+    plain = kn.load_file(str(src), "\t")
+    info = {}
+    first = kn.load_file(str(src), "\t", cache=str(cache), info=info)
+    assert info["from_cache"] is False and cache.exists()
+    second = kn.load_file(str(src), "\t", cache=str(cache), info=info)
+    assert info["from_cache"] is True
+    for a, b, c in zip(plain, first, second):
+        assert np.array_equal(a, b) and np.array_equal(a, c) and a.dtype == c.dtype
+    # another separator: the cache is stamped with the one it was split on
+    other = kn.load_file(str(src), ",", cache=str(cache), info=info)  # (no ',' in the file: no line's column 0 is an Int)
+    assert info["from_cache"] is False and len(other[0]) == 0
+    back = kn.load_file(str(src), "\t", cache=str(cache), info=info)  # the cache now belongs to the ',' parse: not used
+    assert info["from_cache"] is False and np.array_equal(back[0], plain[0])
+    kn.load_file(str(src), "\t", cache=str(cache), info=info)
+    assert info["from_cache"] is True
+    # a corrupted and a truncated cache are ignored and rewritten
+    blob = bytearray(cache.read_bytes())
+    blob[-9] ^= 0x40
+    cache.write_bytes(bytes(blob))
+    again = kn.load_file(str(src), "\t", cache=str(cache), info=info)
+    assert info["from_cache"] is False and np.array_equal(again[2], plain[2])
+    cache.write_bytes(cache.read_bytes()[:-100])
+    kn.load_file(str(src), "\t", cache=str(cache), info=info)
+    assert info["from_cache"] is False
+    kn.load_file(str(src), "\t", cache=str(cache), info=info)
+    assert info["from_cache"] is True
+    # the file changes (one more row): stale cache, re-parsed, re-stamped
+    with open(src, "a") as fh:
+        fh.write("7\t9\t4.5\n")
+    grown = kn.load_file(str(src), "\t", cache=str(cache), info=info)
+    assert info["from_cache"] is False and len(grown[0]) == len(plain[0]) + 1 and grown[2][-1] == 4.5
+    cached = kn.load_file(str(src), "\t", cache=str(cache), info=info)
+    assert info["from_cache"] is True and np.array_equal(cached[0], grown[0])
+    # no cache path: the plain loader
+    assert np.array_equal(kn.load_file(str(src), "\t", cache=None)[1], grown[1])
+
+
 @pytest.mark.gpu
 def test_neighbour_checkpoint_round_trip(kn, oracle, synth, tmp_path):
     """save after a full build, load into a fresh handle fitted on the same rows: identical lists and predictions with
