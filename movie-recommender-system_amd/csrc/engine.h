@@ -89,7 +89,7 @@ struct Train {
 };
 
 // status word bits written by kernels
-enum : uint32_t { ST_NONFINITE = 1u, ST_DUPLICATE = 2u, ST_NOT_DYADIC = 4u, ST_SMALL_ROW = 8u };
+enum : uint32_t { ST_NONFINITE = 1u, ST_DUPLICATE = 2u, ST_NOT_DYADIC = 4u, ST_SMALL_ROW = 8u, ST_LONG_ROW = 16u };
 
 struct PrepScratch {
     SortWorkspace sort;
@@ -99,6 +99,7 @@ struct PrepScratch {
     DArr<uint32_t> perm_f;
     DArr<uint32_t> status;  // [4] device status words
     DArr<int32_t> idrange;  // [4] min / max raw user id, min / max raw item id
+    DArr<int32_t> long_rows;  // [2 (U + 1)] users whose segment is sorted by the wider classes of k_user_hash_order
     DArr<double> dsum;      // small reduction scratch
     DArr<uint4> rec;        // [2 n] (preprocessed rating, deviation | user, file row) records: one 32-byte gather per entry
     void release_all();

@@ -22,7 +22,7 @@ static inline int nblocks(int64_t n, int per = TPB) { return (int)std::max<int64
 void PrepScratch::release_all() {
     sort.tmp.release();
     k64_a.release(); k64_b.release(); v32_a.release(); v32_b.release();
-    k32_a.release(); k32_b.release(); du_row.release(); di_row.release(); perm_f.release(); rec.release();
+    k32_a.release(); k32_b.release(); du_row.release(); di_row.release(); perm_f.release(); rec.release(); long_rows.release();
 }
 
 // ---- K0: ids ---------------------------------------------------------------------------
@@ -178,6 +178,100 @@ __global__ void k_slice_hash_keys(int64_t m, int32_t lo, const uint32_t* __restr
     if (j >= m) return;
     const uint32_t p = pos[j], t = s_t[p];
     key[j] = ((uint64_t)(uint32_t)(s_user[p] - lo) << 32) | tuple_trie_key(users[t], items[t]);
+}
+
+// ---- (user, HashMap order) positions by a sort of every user's own segment in LDS ---------------------------------
+// perm_uh is the canonical positions re-ordered, inside every user, by (trie key of the (user, item) tuple hash, file row).
+// As a global radix sort that is 7 passes over 20 M (64-bit key, value) pairs; but the canonical order already groups the
+// positions by user, and a user's segment (123 ratings on average) fits in LDS: one wave sorts one segment (bitonic network
+// over 64-bit keys (trie key << 32 | file row) with the local index riding along; no workgroup barrier), a whole workgroup
+// the few segments beyond SEG_WAVE_CAP.  A segment longer than SEG_BLOCK_CAP sets ST_LONG_ROW and the fit falls back to
+// the global sort.
+static constexpr int SEG_SHORT_CAP = 512;    // class 0: one wave per segment, every user (5 KB of LDS per wave)
+static constexpr int SEG_MID_CAP = 2048;     // class 1: one workgroup per segment of the middle list (20 KB: eight per CU)
+static constexpr int SEG_BLOCK_CAP = 8192;   // class 2: one workgroup per segment of the long list (80 KB)
+// (powers of two: a segment is padded to the next one for the network)
+
+template <int THREADS, bool BLOCK>
+__device__ __forceinline__ void segment_bitonic(unsigned long long* key, uint16_t* val, int32_t N, int tid) {
+    auto sync = [] {
+        if (BLOCK) {
+            __syncthreads();
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+    for (int32_t size = 2; size <= N; size <<= 1) {
+        for (int32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            sync();
+            for (int32_t t = tid; t < (N >> 1); t += THREADS) {
+                const int32_t lo = 2 * t - (t & (stride - 1));
+                const int32_t hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const unsigned long long a = key[lo], b = key[hi];
+                if ((a > b) == up) {
+                    key[lo] = b; key[hi] = a;
+                    const uint16_t va = val[lo], vb = val[hi];
+                    val[lo] = vb; val[hi] = va;
+                }
+            }
+        }
+    }
+    sync();
+}
+
+struct SegLists {
+    int32_t* mid;        // users of class 1
+    int32_t* longs;      // users of class 2
+    uint32_t* counts;    // [0] = |mid|, [1] = |longs|
+};
+
+// CLASS 0 walks every user (one wave each) and files the longer segments into the two lists; CLASS 1 / 2 walk their list
+// (a workgroup per entry, grid-stride: the list's length stays on the device).
+template <int CLASS>
+__global__ void __launch_bounds__(TPB) k_user_hash_order(const int64_t* __restrict__ u_ptr, int32_t U, SegLists L,
+                                                         const int32_t* __restrict__ uid, const int32_t* __restrict__ iid,
+                                                         const int32_t* __restrict__ s_col, const uint32_t* __restrict__ s_t,
+                                                         uint32_t* __restrict__ perm_uh, uint32_t* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) char seg_smem[];
+    constexpr bool BLOCK = CLASS >= 1;
+    constexpr int CAP = CLASS == 0 ? SEG_SHORT_CAP : CLASS == 1 ? SEG_MID_CAP : SEG_BLOCK_CAP;
+    constexpr int THREADS = BLOCK ? TPB : 64;
+    constexpr int SEGS = BLOCK ? 1 : TPB / 64;  // segments in flight per workgroup
+    const int wave = BLOCK ? 0 : (int)(threadIdx.x >> 6);
+    const int tid = BLOCK ? (int)threadIdx.x : (int)(threadIdx.x & 63);
+    unsigned long long* key = reinterpret_cast<unsigned long long*>(seg_smem) + (size_t)wave * CAP;
+    uint16_t* val = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned long long*>(seg_smem) + (size_t)SEGS * CAP) + (size_t)wave * CAP;
+    const int64_t total = CLASS == 0 ? (int64_t)U : (int64_t)L.counts[CLASS - 1];
+    for (int64_t idx = (int64_t)blockIdx.x * SEGS + wave; idx < total; idx += (int64_t)gridDim.x * SEGS) {
+        const int32_t u = CLASS == 0 ? (int32_t)idx : (CLASS == 1 ? L.mid[idx] : L.longs[idx]);
+        const int64_t b = u_ptr[u], e = u_ptr[u + 1];
+        const int64_t n64 = e - b;
+        if (n64 > CAP) {  // (only class 0 meets these)
+            if (tid == 0) {
+                if (n64 <= SEG_MID_CAP) L.mid[atomicAdd(&L.counts[0], 1u)] = u;
+                else if (n64 <= SEG_BLOCK_CAP) L.longs[atomicAdd(&L.counts[1], 1u)] = u;
+                else atomicOr(status, (uint32_t)ST_LONG_ROW);
+            }
+            continue;
+        }
+        const int32_t n = (int32_t)n64;
+        int32_t N = 2;
+        while (N < n) N <<= 1;
+        const int32_t user_raw = uid[u];
+        for (int32_t i = tid; i < N; i += THREADS) {
+            unsigned long long k = ~0ull;
+            if (i < n) k = ((unsigned long long)tuple_trie_key(user_raw, iid[s_col[b + i]]) << 32) | s_t[b + i];
+            key[i] = k;
+            val[i] = (uint16_t)i;
+        }
+        segment_bitonic<THREADS, BLOCK>(key, val, N, tid);
+        for (int32_t i = tid; i < n; i += THREADS) perm_uh[b + i] = (uint32_t)(b + val[i]);
+        // (the next segment's stores into key / val follow this wave's / workgroup's reads in program order; the workgroup
+        // form needs its barrier)
+        if (BLOCK) __syncthreads();
+    }
 }
 
 // 32-bit keys for the two plain fold orders (a third less sort traffic than 64-bit keys)
@@ -449,10 +543,15 @@ void prep_fit(Train& tr, PrepScratch& sc, int32_t shard_rank, int32_t shard_coun
         KN_HIP(hipMemcpyAsync(sc.idrange.p, init, sizeof(init), hipMemcpyHostToDevice, st));
     }
     k_id_range<<<(unsigned)std::min<int64_t>(1024, ceil_div(n, TPB)), TPB, 0, st>>>(n, tr.user_raw.p, tr.item_raw.p, sc.idrange.p);
+    // (K1 / K2 sum ratings: exact in any order when they are dyadic — checked here, read back with the id range)
+    k_check_dyadic<<<nblocks(n), TPB, 0, st>>>(n, tr.rating.p, sc.status.p);
     KN_HIP(hipGetLastError());
     int32_t rg[4];
+    uint32_t early_status = 0;
     KN_HIP(hipMemcpyAsync(rg, sc.idrange.p, sizeof(rg), hipMemcpyDeviceToHost, st));
+    KN_HIP(hipMemcpyAsync(&early_status, sc.status.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     KN_HIP(hipStreamSynchronize(st));
+    const bool dyadic = !(early_status & ST_NOT_DYADIC);
     const int32_t ID_LIMIT = 1 << 24;
     const bool small_ids = rg[0] >= 0 && rg[2] >= 0 && rg[1] < ID_LIMIT && rg[3] < ID_LIMIT && !getenv("KNNCF_DEBUG_NO_ID_TABLES");
     tr.u_table_n = tr.i_table_n = 0;
@@ -564,10 +663,16 @@ void prep_fit(Train& tr, PrepScratch& sc, int32_t shard_rank, int32_t shard_coun
 
     // fold orders: stable sorts of the file-order sequence of positions
     // (the item-side fold orders belong to K4, which only the baseline predictors use: prep_item_stats)
-    tr.perm_uf.alloc(n);
+    // usersAvg :113 sums a user's ratings in file order; dyadic ratings (every MovieLens file) sum exactly in ANY order, so a
+    // whole-file fit then folds them in the canonical order and never builds the (user, file row) order
+    const bool need_uf = !dyadic || n <= 4 || shard_count > 1;
+    if (need_uf) tr.perm_uf.alloc(n);
+    else tr.perm_uf.release();
     if (shard_count == 1) {
-        k_copy_keys_u32<<<nblocks(n), TPB, 0, st>>>(n, sc.du_row.p, sc.k32_a.p);
-        sort_pairs_u32_u32(sc.sort, sc.k32_a.p, sc.k32_b.p, sc.perm_f.p, tr.perm_uf.p, n, ubits, st);
+        if (need_uf) {
+            k_copy_keys_u32<<<nblocks(n), TPB, 0, st>>>(n, sc.du_row.p, sc.k32_a.p);
+            sort_pairs_u32_u32(sc.sort, sc.k32_a.p, sc.k32_b.p, sc.perm_f.p, tr.perm_uf.p, n, ubits, st);
+        }
     } else if (p1 > p0) {
         // A shard folds its own users only (K2, K3 below), so it orders only their positions: the slice [p0, p1) of the
         // canonical order by (user, file row) — the same segments the whole-file sort yields, 1/shards of the work.
@@ -577,9 +682,24 @@ void prep_fit(Train& tr, PrepScratch& sc, int32_t shard_rank, int32_t shard_coun
         sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.v32_a.p, tr.perm_uf.p + p0, p1 - p0, tbits + bits_for((uint64_t)(hi - lo)), st);
     }
     KN_HIP(hipGetLastError());
+    bool segment_sorted = false;
     if (n > 4) {  // a Map of <= 4 entries (Map1..Map4) iterates in insertion = file order (N4)
         tr.perm_uh.alloc(n);
-        if (shard_count == 1) {
+        if (shard_count == 1 && !getenv("KNNCF_DEBUG_GLOBAL_HASH_ORDER")) {
+            // every user's segment sorted in LDS (three size classes; a segment beyond the last one -> ST_LONG_ROW, below)
+            sc.long_rows.ensure(2 * (size_t)U + 2);
+            KN_HIP(hipMemsetAsync(sc.status.p + 2, 0, 2 * sizeof(uint32_t), st));  // (words 2, 3: the two list lengths)
+            SegLists L{sc.long_rows.p, sc.long_rows.p + U + 1, sc.status.p + 2};
+            static PerDeviceState lds1, lds2;
+            const size_t smem0 = (size_t)(TPB / 64) * SEG_SHORT_CAP * 10, smem1 = (size_t)SEG_MID_CAP * 10, smem2 = (size_t)SEG_BLOCK_CAP * 10;
+            ensure_dynamic_lds(lds1, (const void*)k_user_hash_order<1>, smem1);
+            ensure_dynamic_lds(lds2, (const void*)k_user_hash_order<2>, smem2);
+            k_user_hash_order<0><<<nblocks(U, TPB / 64), TPB, smem0, st>>>(tr.u_ptr.p, tr.U, L, tr.uid.p, tr.iid.p, tr.s_col.p, tr.s_t.p, tr.perm_uh.p, sc.status.p);
+            k_user_hash_order<1><<<2048, TPB, smem1, st>>>(tr.u_ptr.p, tr.U, L, tr.uid.p, tr.iid.p, tr.s_col.p, tr.s_t.p, tr.perm_uh.p, sc.status.p);
+            k_user_hash_order<2><<<256, TPB, smem2, st>>>(tr.u_ptr.p, tr.U, L, tr.uid.p, tr.iid.p, tr.s_col.p, tr.s_t.p, tr.perm_uh.p, sc.status.p);
+            KN_HIP(hipGetLastError());
+            segment_sorted = true;
+        } else if (shard_count == 1) {
             k_make_keys<<<nblocks(n), TPB, 0, st>>>(n, 2, sc.du_row.p, sc.di_row.p, tr.user_raw.p, tr.item_raw.p, sc.k64_a.p, 32);
             sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.perm_f.p, tr.perm_uh.p, n, 32 + ubits, st);
         } else if (p1 > p0) {  // the slice in (user, file row) order, stably re-sorted by (user, trie key)
@@ -595,11 +715,14 @@ void prep_fit(Train& tr, PrepScratch& sc, int32_t shard_rank, int32_t shard_coun
     tr.item_stats_ready = false;
 
     // K1: average :94 — left fold over the file; exact in any order for dyadic ratings
-    k_check_dyadic<<<nblocks(n), TPB, 0, st>>>(n, tr.rating.p, sc.status.p);
     if (shard_count > 1) k_flag_small_rows<<<nblocks(tr.U), TPB, 0, st>>>(tr.U, tr.u_ptr.p, sc.status.p);
     KN_HIP(hipGetLastError());
     uint32_t status = read_status(sc, st);
     KN_REQUIRE(!(status & ST_DUPLICATE), KNNCF_E_DUPLICATE, "fit: duplicate (user,item) training rows");
+    if (segment_sorted && (status & ST_LONG_ROW)) {  // a user with more ratings than a workgroup sorts in LDS: the global sort
+        k_make_keys<<<nblocks(n), TPB, 0, st>>>(n, 2, sc.du_row.p, sc.di_row.p, tr.user_raw.p, tr.item_raw.p, sc.k64_a.p, 32);
+        sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.perm_f.p, tr.perm_uh.p, n, 32 + ubits, st);
+    }
     // The summation order of a pair with a <= 4-rating user follows the memo history of the reference's closures; a single
     // handle models it (nbr_seq), but the shards do not exchange their build sequence numbers: refused rather than
     // answered differently from the single-GPU run.  Every rank holds all rows, so every rank refuses alike.
@@ -624,7 +747,7 @@ void prep_fit(Train& tr, PrepScratch& sc, int32_t shard_rank, int32_t shard_coun
     }
     if (hi > lo) {
         // K2: usersAvg :113 (groupBy keeps file order; mean = reduce(_+_) / length)
-        fold<false>(tr.u_ptr.p, lo, hi, tr.perm_uf.p, tr.s_rating.p, tr.user_norm.p, st);
+        fold<false>(tr.u_ptr.p, lo, hi, need_uf ? tr.perm_uf.p : nullptr, tr.s_rating.p, tr.user_norm.p, st);
         k_divide_by_count<<<nblocks(hi - lo), TPB, 0, st>>>(tr.u_ptr.p, lo, hi, tr.user_norm.p, tr.user_avg.p);
         // K3: deviations, norms (HashMap order), preprocessed ratings
         k_deviation<<<nblocks(p1 - p0), TPB, 0, st>>>(p0, p1, tr.s_user.p, tr.s_rating.p, tr.user_avg.p, tr.s_dev.p, sc.status.p);

@@ -450,6 +450,49 @@ def test_ids_outside_the_direct_tables(kn, oracle, synth, monkeypatch):
         e.close()
 
 
+def test_user_rows_of_every_size_class(kn, oracle, monkeypatch):
+    """the (user, HashMap order) positions come from per-user LDS sorts in three size classes (<= 512, <= 2048, <= 8192
+    ratings) and from the global radix sort when a user has more: users of 9 000, 3 000, 1 000 and ~60 ratings in one file;
+    the norms (hence every similarity, bit for bit) depend on that order.  Also with the global sort forced for everyone,
+    and with non-dyadic ratings (then usersAvg really folds in file order)."""
+    rng = np.random.default_rng(11)
+    n_items = 10_000
+    users, items = [], []
+    for u, cnt in [(1, 9_000), (2, 3_000), (3, 1_000)] + [(10 + j, int(rng.integers(30, 90))) for j in range(40)]:
+        its = rng.choice(n_items, size=cnt, replace=False) + 1
+        users += [u] * cnt
+        items += its.tolist()
+    users, items = np.asarray(users, np.int32), np.asarray(items, np.int32)
+    order = rng.permutation(len(users))
+    users, items = users[order], items[order]
+    for dyadic in (True, False):
+        ratings = rng.integers(1, 11, size=len(users)) / 2.0
+        if not dyadic:
+            ratings = ratings + rng.integers(0, 7, size=len(users)) * 0.1  # (sums now depend on the order)
+            ratings = np.minimum(ratings, 5.0)
+        cut = len(users) * 9 // 10
+        tr = (users[:cut], items[:cut], ratings[:cut])
+        te = (users[cut:], items[cut:], ratings[cut:])
+        p = oracle.Model(*tr).pipeline(oracle.SIM_COSINE, 10)
+        want, preds = p.mae(*te, True)
+        for forced in (False, True):
+            if forced:
+                monkeypatch.setenv("KNNCF_DEBUG_GLOBAL_HASH_ORDER", "1")
+            else:
+                monkeypatch.delenv("KNNCF_DEBUG_GLOBAL_HASH_ORDER", raising=False)
+            e = _engine(kn, tr, k=10)
+            np.testing.assert_array_equal(e.predict_batch(kn.PRED_KNN, te[0], te[1]), preds)
+            assert abs(e.mae(kn.PRED_KNN, *te) - want) <= MAE_TOL
+            m2 = oracle.Model(*tr)
+            p2 = m2.pipeline(oracle.SIM_COSINE, 10)
+            for u in (1, 2, 3, 10, 25, 49):
+                ids, sims = e.neighbors(u)
+                oids, osims = p2.neighbors(u)
+                assert ids.tolist() == oids.tolist() and sims.tolist() == osims.tolist()
+                assert e.user_avg(u) == m2.users_avg(u)
+            e.close()
+
+
 def test_prediction_without_item_bitmaps(kn, oracle, synth, monkeypatch):
     """shapes whose rater bitmaps would not fit in HBM predict through binary searches (k_predict_knn): forced here"""
     monkeypatch.setenv("KNNCF_DEBUG_NO_ITEM_BITMAPS", "1")
