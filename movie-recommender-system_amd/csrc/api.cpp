@@ -349,10 +349,12 @@ void build_neighbors(knncf_handle* h, int32_t count) {
     const int32_t head = h->head;
     h->tm.head_items = head;
     if (use_sym) {
-        const int32_t n_tiles = (int32_t)(U_pad / 256);
+        static const bool tile128 = getenv("KNNCF_GEMM_SYM_TILE128") != nullptr;  // A/B switch for measurements
+        const int sym_tile = (tile128 && fp16 && s_fp16) ? 128 : 256;
+        const int32_t n_tiles = (int32_t)(U_pad / sym_tile);
         if (h->sym_tiles_n != n_tiles) {
             std::vector<uint32_t> list;
-            gemm_sym_tile_list(n_tiles, list);
+            gemm_sym_tile_list(n_tiles, list, sym_tile == 128 ? 16 : 8);
             h->sym_tiles.ensure(list.size());
             KN_HIP(hipMemcpyAsync(h->sym_tiles.p, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
             KN_HIP(hipStreamSynchronize(st));
@@ -360,9 +362,9 @@ void build_neighbors(knncf_handle* h, int32_t count) {
         }
         const int64_t n_listed = (int64_t)n_tiles * (n_tiles + 1) / 2;
         Stage s(h, &h->tm.gemm_ms);
-        launch_gemm_sym(h->Bpanel.p, h->S_full.p, s_fp16, U_pad, h->K_pad, h->K_pad, U_pad, fp16, !tr.jaccard, h->sym_tiles.p, n_listed, st);
+        launch_gemm_sym(h->Bpanel.p, h->S_full.p, s_fp16, U_pad, h->K_pad, h->K_pad, U_pad, fp16, !tr.jaccard, h->sym_tiles.p, n_listed, st, sym_tile);
         h->tm.gemm_launches += 1;
-        h->tm.gemm_flops_executed += 2.0 * 65536.0 * (double)n_listed * (double)h->K_pad;
+        h->tm.gemm_flops_executed += 2.0 * (double)sym_tile * (double)sym_tile * (double)n_listed * (double)h->K_pad;
         // ordered pairs (row, other user) of the rows actually wanted x the dense columns (bench.py halves it)
         h->tm.gemm_flops_algorithmic += 2.0 * (double)count * (double)(tr.U - 1) * (double)h->head;
         KN_HIP(hipMemGetInfo(&free_b, &total_b));

@@ -132,9 +132,9 @@ void launch_gemm_nt(const bf16_t* A, const bf16_t* B, void* C, bool c_fp16, int6
 
 // the whole symmetric matrix at once: C[N][ldc] = B B^T computed on and above the diagonal (256 x 256 tiles in the order of
 // the tile list) and mirrored below it; the stored values are bit for bit those of launch_gemm_nt(B, B, ...)
-void gemm_sym_tile_list(int32_t n_tiles, std::vector<uint32_t>& out);
+void gemm_sym_tile_list(int32_t n_tiles, std::vector<uint32_t>& out, int32_t group = 8);
 void launch_gemm_sym(const bf16_t* B, void* C, bool c_fp16, int64_t N, int64_t K, int64_t ldb, int64_t ldc, bool fp16, bool clamp,
-                     const uint32_t* d_tile_list, int64_t n_listed, hipStream_t st);
+                     const uint32_t* d_tile_list, int64_t n_listed, hipStream_t st, int tile = 256);
 
 // ---- select.hip: K6 + K6b --------------------------------------------------------------
 struct NeighborTable {

@@ -403,19 +403,24 @@ void launch_gemm_nt(const bf16_t* A, const bf16_t* B, void* C, bool c_fp16, int6
 
 // the 256 x 256 tiles on and above the diagonal of an n_tiles x n_tiles grid, 8 tile rows at a time and column by
 // column inside such a group (the group's operand rows stay in the L2 while its columns stream): tile row | column << 16
-void gemm_sym_tile_list(int32_t n_tiles, std::vector<uint32_t>& out) {
+void gemm_sym_tile_list(int32_t n_tiles, std::vector<uint32_t>& out, int32_t group) {
     out.clear();
     out.reserve((size_t)n_tiles * (n_tiles + 1) / 2);
-    for (int32_t g = 0; g < n_tiles; g += 8)
+    for (int32_t g = 0; g < n_tiles; g += group)
         for (int32_t tn = g; tn < n_tiles; ++tn)
-            for (int32_t tm = g; tm < std::min(g + 8, n_tiles) && tm <= tn; ++tm) out.push_back((uint32_t)tm | ((uint32_t)tn << 16));
+            for (int32_t tm = g; tm < std::min(g + group, n_tiles) && tm <= tn; ++tm) out.push_back((uint32_t)tm | ((uint32_t)tn << 16));
 }
 
 // S[N x N] = B B^T for all N rows at once, N a multiple of 256, computed on and above the diagonal and mirrored
 // (fp16 panel storage only: the path that holds the whole similarity matrix)
 void launch_gemm_sym(const bf16_t* B, void* C, bool c_fp16, int64_t N, int64_t K, int64_t ldb, int64_t ldc, bool fp16, bool clamp,
-                     const uint32_t* d_tile_list, int64_t n_listed, hipStream_t st) {
-    KN_REQUIRE(N % 256 == 0 && N / 256 < 65536 && K % BK == 0 && K > 0 && ldb % 8 == 0 && ldc % 8 == 0, KNNCF_E_INVALID, "symmetric gemm: shape not tile-aligned");
+                     const uint32_t* d_tile_list, int64_t n_listed, hipStream_t st, int tile) {
+    KN_REQUIRE(N % 256 == 0 && N / 128 < 65536 && K % BK == 0 && K > 0 && ldb % 8 == 0 && ldc % 8 == 0, KNNCF_E_INVALID, "symmetric gemm: shape not tile-aligned");
+    if (tile == 128) {  // two workgroups per CU: one's stores run under the other's MFMA steps
+        KN_REQUIRE(fp16 && c_fp16, KNNCF_E_INVALID, "symmetric gemm: the 128-tile form is built for fp16 operands and panel");
+        launch_gemm_cfg<true, _Float16, 2, 2, 2, 2, true>(B, B, static_cast<_Float16*>(C), N, N, K, ldb, ldb, ldc, d_tile_list, n_listed, clamp, st);
+        return;
+    }
     if (fp16 && c_fp16) launch_gemm_cfg<true, _Float16, 4, 2, 2, 4, true>(B, B, static_cast<_Float16*>(C), N, N, K, ldb, ldb, ldc, d_tile_list, n_listed, clamp, st);
     else if (fp16) launch_gemm_cfg<true, float, 4, 2, 2, 4, true>(B, B, static_cast<float*>(C), N, N, K, ldb, ldb, ldc, d_tile_list, n_listed, clamp, st);
     else if (c_fp16) launch_gemm_cfg<false, _Float16, 4, 2, 2, 4, true>(B, B, static_cast<_Float16*>(C), N, N, K, ldb, ldb, ldc, d_tile_list, n_listed, clamp, st);
