@@ -16,7 +16,7 @@ namespace knncf {
 // small kernels of the orchestrator (neighbours.hip)
 void launch_first_rows(int64_t n, const int32_t* d_du, const int32_t* d_di, int32_t own_lo, int32_t own_hi,
                        uint32_t* d_first, hipStream_t st);
-void launch_length_keys(int32_t count, const int32_t* d_list, const int64_t* d_u_ptr, uint64_t* d_key, hipStream_t st);
+void launch_length_keys(int32_t count, const int32_t* d_list, const int64_t* d_u_ptr, int32_t max_len, uint64_t* d_key, hipStream_t st);
 void launch_collect_new(int32_t U, const uint32_t* d_first, int64_t* d_seq, int64_t epoch, int32_t* d_list,
                         int32_t* d_count, hipStream_t st);
 void launch_fallback_keys(int32_t U, const double* d_exact, uint64_t* d_keys, uint32_t* d_vals, hipStream_t st);
@@ -290,8 +290,8 @@ void build_neighbors(knncf_handle* h, int32_t count) {
         // The order of the list carries no meaning (the users' build sequence numbers are already assigned).
         PrepScratch& sc = h->prep;
         sc.k64_a.ensure(count); sc.k64_b.ensure(count); sc.v32_b.ensure(count);
-        launch_length_keys(count, h->build_list.p, tr.u_ptr.p, sc.k64_a.p, st);
-        sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, reinterpret_cast<const uint32_t*>(h->build_list.p), sc.v32_b.p, count, 32, st);
+        launch_length_keys(count, h->build_list.p, tr.u_ptr.p, tr.I, sc.k64_a.p, st);  // (a row holds every item at most once)
+        sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, reinterpret_cast<const uint32_t*>(h->build_list.p), sc.v32_b.p, count, bits_for((uint64_t)tr.I), st);
         KN_HIP(hipMemcpyAsync(h->build_list.p, sc.v32_b.p, (size_t)count * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     }
     const bool fp16 = (h->cfg.flags & KNNCF_FLAG_BF16_FILTER) == 0;
@@ -601,6 +601,7 @@ void run_predict(knncf_handle* h, int predictor, const int32_t* d_users, const i
         if (kind == KNNCF_PRED_KNN) {  // rows sorted by item (the item's rater bitmap lives in LDS) or else by user
             PrepScratch& sc = h->prep;
             sc.k64_a.ensure(n); sc.k64_b.ensure(n); sc.v32_a.ensure(n); sc.v32_b.ensure(n);
+            const uint32_t key_limit = (uint32_t)(by_item ? tr.I : tr.U);  // the key of a row whose item / user the train set lacks
             if (h->cfg.shard_count > 1) {
                 // the test set is replicated on every shard, the work is not: this shard's rows sort first and only they are
                 // predicted; the other rows' error / ownership cells are cleared here instead of by the kernel
@@ -608,13 +609,13 @@ void run_predict(knncf_handle* h, int predictor, const int32_t* d_users, const i
                 KN_HIP(hipMemsetAsync(h->scalar_u64.p, 0, sizeof(unsigned long long), st));
                 KN_HIP(hipMemsetAsync(h->t_err.p, 0, (size_t)n * sizeof(double), st));
                 KN_HIP(hipMemsetAsync(h->t_owned.p, 0, (size_t)n, st));
-                launch_owned_keys(n, by_item ? h->t_di.p : h->t_du.p, h->t_du.p, tr.own_lo, tr.own_hi, h->cfg.shard_rank == 0,
+                launch_owned_keys(n, by_item ? h->t_di.p : h->t_du.p, h->t_du.p, tr.own_lo, tr.own_hi, h->cfg.shard_rank == 0, key_limit,
                                   sc.k64_a.p, sc.v32_a.p, h->scalar_u64.p, st);
-                sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.v32_a.p, sc.v32_b.p, n, 33, st);
+                sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.v32_a.p, sc.v32_b.p, n, bits_for((uint64_t)key_limit + 1), st);
                 n_rows = (int64_t)fetch(h, h->scalar_u64.p, 0);
             } else {
-                launch_user_keys(n, by_item ? h->t_di.p : h->t_du.p, sc.k64_a.p, sc.v32_a.p, st);
-                sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.v32_a.p, sc.v32_b.p, n, 32, st);
+                launch_user_keys(n, by_item ? h->t_di.p : h->t_du.p, key_limit, sc.k64_a.p, sc.v32_a.p, st);
+                sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.v32_a.p, sc.v32_b.p, n, bits_for((uint64_t)key_limit), st);
             }
             d_order = sc.v32_b.p;
         }

@@ -171,6 +171,12 @@ inline void ensure_dynamic_lds(PerDeviceState& state, const void* kernel, size_t
     });
 }
 
+// bits of the largest key value: the fewer significant key bits a radix sort is told, the fewer passes it runs
+inline int bits_for(uint64_t max_value) {
+    int b = 1;
+    while (b < 64 && (max_value >> b) != 0) ++b;
+    return b;
+}
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
 

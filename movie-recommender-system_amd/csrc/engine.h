@@ -19,7 +19,7 @@ inline int32_t select_gcap(int32_t k) { return 8192 * (int32_t)((k + 511) / 512 
 #endif
 static constexpr int SELECT_TCOLS = KNNCF_TCOLS;  // <= 2^15: it_pack keeps the LDS cell of the column inside its tile in 15 bits
 
-// ---- sort_util.hip (rocPRIM device radix sort / unique; K0 plumbing only) ---------------
+// ---- sort_util.hip (stable LSD radix sort / sorted-unique, hand-written; K0 plumbing) ----
 struct SortWorkspace {
     DArr<char> tmp;
     DArr<size_t> count;  // result cell of unique_u32 (kept: a hipFree per call synchronises the device)
@@ -99,6 +99,7 @@ struct PrepScratch {
     DArr<uint32_t> perm_f;
     DArr<uint32_t> status;  // [4] device status words
     DArr<int32_t> idrange;  // [4] min / max raw user id, min / max raw item id
+    DArr<uint32_t> ucnt, utile;  // [U] ratings per user (then the scatter cursors), [U / 2048] their sums per tile
     DArr<int32_t> long_rows;  // [2 (U + 1)] users whose segment is sorted by the wider classes of k_user_hash_order
     DArr<double> dsum;      // small reduction scratch
     DArr<uint4> rec;        // [2 n] (preprocessed rating, deviation | user, file row) records: one 32-byte gather per entry
@@ -203,11 +204,12 @@ void launch_predict(const Train& tr, const NeighborTable* nt, int predictor, int
                     const int32_t* d_du, const int32_t* d_di, const double* d_ratings,
                     const uint32_t* d_order, bool order_by_item, double* d_pred, double* d_abs_err, uint8_t* d_owned,
                     bool unknown_users_owned, hipStream_t st);
-// (key, value) = (dense user or 2^32-1, row) of every test row: sorted, it is the d_order of the grouped kNN kernel
-void launch_user_keys(int64_t n, const int32_t* d_du, uint64_t* d_key, uint32_t* d_val, hipStream_t st);
-// sharded handles: key = d_src (dense user or item) for the rows of this shard's users, 2^32 for everybody else's;
+// (key, value) = (dense user / item, or `limit` (= their number) when absent from train; row) of every test row: sorted
+// (bits_for(limit + 1) key bits), it is the d_order of the grouped kNN kernels
+void launch_user_keys(int64_t n, const int32_t* d_du, uint32_t limit, uint64_t* d_key, uint32_t* d_val, hipStream_t st);
+// sharded handles: key = d_src (dense user or item) for the rows of this shard's users, limit + 1 for everybody else's;
 // *d_n_owned += number of rows of this shard
-void launch_owned_keys(int64_t n, const int32_t* d_src, const int32_t* d_du, int32_t own_lo, int32_t own_hi, bool unknown_owned,
+void launch_owned_keys(int64_t n, const int32_t* d_src, const int32_t* d_du, int32_t own_lo, int32_t own_hi, bool unknown_owned, uint32_t limit,
                        uint64_t* d_key, uint32_t* d_val, unsigned long long* d_n_owned, hipStream_t st);
 // deterministic fixed-shape reduction: sum of d_abs_err and count of d_owned
 void launch_reduce_err(const double* d_abs_err, const uint8_t* d_owned, int64_t n, double* d_partials,

@@ -55,16 +55,16 @@ void launch_collect_new(int32_t U, const uint32_t* d_first, int64_t* d_seq, int6
 
 // sort key of a build list by DESCENDING number of ratings (longest rows first: the select and re-rank kernels run
 // one workgroup per row, and a 7000-rating row dispatched last would hold the launch open alone)
-__global__ void k_length_keys(int32_t count, const int32_t* __restrict__ list, const int64_t* __restrict__ u_ptr,
+__global__ void k_length_keys(int32_t count, const int32_t* __restrict__ list, const int64_t* __restrict__ u_ptr, int32_t max_len,
                               uint64_t* __restrict__ key) {
     int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= count) return;
     const int32_t u = list[r];
-    key[r] = 0xffffffffull - (uint64_t)(uint32_t)(u_ptr[u + 1] - u_ptr[u]);
+    key[r] = (uint64_t)max_len - (uint64_t)(u_ptr[u + 1] - u_ptr[u]);
 }
 
-void launch_length_keys(int32_t count, const int32_t* d_list, const int64_t* d_u_ptr, uint64_t* d_key, hipStream_t st) {
-    k_length_keys<<<(unsigned)ceil_div(count, TPB), TPB, 0, st>>>(count, d_list, d_u_ptr, d_key);
+void launch_length_keys(int32_t count, const int32_t* d_list, const int64_t* d_u_ptr, int32_t max_len, uint64_t* d_key, hipStream_t st) {
+    k_length_keys<<<(unsigned)ceil_div(count, TPB), TPB, 0, st>>>(count, d_list, d_u_ptr, max_len, d_key);
     KN_HIP(hipGetLastError());
 }
 

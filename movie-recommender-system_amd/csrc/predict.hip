@@ -615,37 +615,37 @@ __global__ void __launch_bounds__(WAVES * 64) k_predict_knn_items(PredArgs A, in
 }
 
 // sort key of a test row: its dense user / item (unknown ones last)
-__global__ void k_user_keys(int64_t n, const int32_t* __restrict__ du, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
+__global__ void k_user_keys(int64_t n, const int32_t* __restrict__ du, uint32_t limit, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    key[t] = du[t] < 0 ? 0xffffffffull : (uint64_t)(uint32_t)du[t];
+    key[t] = du[t] < 0 ? (uint64_t)limit : (uint64_t)(uint32_t)du[t];
     val[t] = (uint32_t)t;
 }
 
-// the same for a shard: rows of other shards' users sort behind everything (key 2^32) and are counted out, so that the
+// the same for a shard: rows of other shards' users sort behind everything (key limit + 1) and are counted out, so that the
 // prediction kernel only ever sees this shard's rows (the test set is replicated on every rank, the work is not)
 __global__ void k_owned_keys(int64_t n, const int32_t* __restrict__ src, const int32_t* __restrict__ du, int32_t own_lo, int32_t own_hi,
-                             int unknown_owned, uint64_t* __restrict__ key, uint32_t* __restrict__ val, unsigned long long* __restrict__ n_owned) {
+                             int unknown_owned, uint32_t limit, uint64_t* __restrict__ key, uint32_t* __restrict__ val, unsigned long long* __restrict__ n_owned) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool mine = false;
     if (t < n) {
         const int32_t u = du[t];
         mine = (u < 0) ? (unknown_owned != 0) : (u >= own_lo && u < own_hi);
-        key[t] = !mine ? 0x100000000ull : (src[t] < 0 ? 0xffffffffull : (uint64_t)(uint32_t)src[t]);
+        key[t] = !mine ? (uint64_t)limit + 1ull : (src[t] < 0 ? (uint64_t)limit : (uint64_t)(uint32_t)src[t]);
         val[t] = (uint32_t)t;
     }
     const unsigned long long b = __ballot(mine);
     if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_owned, (unsigned long long)__popcll(b));
 }
 
-void launch_owned_keys(int64_t n, const int32_t* d_src, const int32_t* d_du, int32_t own_lo, int32_t own_hi, bool unknown_owned,
+void launch_owned_keys(int64_t n, const int32_t* d_src, const int32_t* d_du, int32_t own_lo, int32_t own_hi, bool unknown_owned, uint32_t limit,
                        uint64_t* d_key, uint32_t* d_val, unsigned long long* d_n_owned, hipStream_t st) {
-    k_owned_keys<<<(unsigned)ceil_div(n, TPB), TPB, 0, st>>>(n, d_src, d_du, own_lo, own_hi, unknown_owned ? 1 : 0, d_key, d_val, d_n_owned);
+    k_owned_keys<<<(unsigned)ceil_div(n, TPB), TPB, 0, st>>>(n, d_src, d_du, own_lo, own_hi, unknown_owned ? 1 : 0, limit, d_key, d_val, d_n_owned);
     KN_HIP(hipGetLastError());
 }
 
-void launch_user_keys(int64_t n, const int32_t* d_du, uint64_t* d_key, uint32_t* d_val, hipStream_t st) {
-    k_user_keys<<<(unsigned)ceil_div(n, TPB), TPB, 0, st>>>(n, d_du, d_key, d_val);
+void launch_user_keys(int64_t n, const int32_t* d_du, uint32_t limit, uint64_t* d_key, uint32_t* d_val, hipStream_t st) {
+    k_user_keys<<<(unsigned)ceil_div(n, TPB), TPB, 0, st>>>(n, d_du, limit, d_key, d_val);
     KN_HIP(hipGetLastError());
 }
 

@@ -22,7 +22,7 @@ static inline int nblocks(int64_t n, int per = TPB) { return (int)std::max<int64
 void PrepScratch::release_all() {
     sort.tmp.release();
     k64_a.release(); k64_b.release(); v32_a.release(); v32_b.release();
-    k32_a.release(); k32_b.release(); du_row.release(); di_row.release(); perm_f.release(); rec.release(); long_rows.release();
+    k32_a.release(); k32_b.release(); du_row.release(); di_row.release(); perm_f.release(); rec.release(); long_rows.release(); ucnt.release(); utile.release();
 }
 
 // ---- K0: ids ---------------------------------------------------------------------------
@@ -192,7 +192,7 @@ static constexpr int SEG_MID_CAP = 2048;     // class 1: one workgroup per segme
 static constexpr int SEG_BLOCK_CAP = 8192;   // class 2: one workgroup per segment of the long list (80 KB)
 // (powers of two: a segment is padded to the next one for the network)
 
-template <int THREADS, bool BLOCK>
+template <int THREADS, bool BLOCK, bool VAL>
 __device__ __forceinline__ void segment_bitonic(unsigned long long* key, uint16_t* val, int32_t N, int tid) {
     auto sync = [] {
         if (BLOCK) {
@@ -212,8 +212,10 @@ __device__ __forceinline__ void segment_bitonic(unsigned long long* key, uint16_
                 const unsigned long long a = key[lo], b = key[hi];
                 if ((a > b) == up) {
                     key[lo] = b; key[hi] = a;
-                    const uint16_t va = val[lo], vb = val[hi];
-                    val[lo] = vb; val[hi] = va;
+                    if (VAL) {
+                        const uint16_t va = val[lo], vb = val[hi];
+                        val[lo] = vb; val[hi] = va;
+                    }
                 }
             }
         }
@@ -227,13 +229,15 @@ struct SegLists {
     uint32_t* counts;    // [0] = |mid|, [1] = |longs|
 };
 
-// CLASS 0 walks every user (one wave each) and files the longer segments into the two lists; CLASS 1 / 2 walk their list
-// (a workgroup per entry, grid-stride: the list's length stays on the device).
-template <int CLASS>
-__global__ void __launch_bounds__(TPB) k_user_hash_order(const int64_t* __restrict__ u_ptr, int32_t U, SegLists L,
+// CLASS 0 walks the users [u_lo, u_hi) (one wave each) and files the longer segments into the two lists; CLASS 1 / 2 walk
+// their list (a workgroup per entry, grid-stride: the list's length stays on the device).  The host only takes this path
+// when no segment exceeds SEG_BLOCK_CAP (prep_fit reads the longest row's length back); ST_LONG_ROW is a consistency check.
+// FILE_ORDER: the key is the file row alone — perm_uf, the (user, file row) order of usersAvg :113.
+template <int CLASS, bool FILE_ORDER>
+__global__ void __launch_bounds__(TPB) k_user_hash_order(const int64_t* __restrict__ u_ptr, int32_t u_lo, int32_t u_hi, SegLists L,
                                                          const int32_t* __restrict__ uid, const int32_t* __restrict__ iid,
                                                          const int32_t* __restrict__ s_col, const uint32_t* __restrict__ s_t,
-                                                         uint32_t* __restrict__ perm_uh, uint32_t* __restrict__ status) {
+                                                         uint32_t* __restrict__ perm_out, uint32_t* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) char seg_smem[];
     constexpr bool BLOCK = CLASS >= 1;
     constexpr int CAP = CLASS == 0 ? SEG_SHORT_CAP : CLASS == 1 ? SEG_MID_CAP : SEG_BLOCK_CAP;
@@ -243,9 +247,9 @@ __global__ void __launch_bounds__(TPB) k_user_hash_order(const int64_t* __restri
     const int tid = BLOCK ? (int)threadIdx.x : (int)(threadIdx.x & 63);
     unsigned long long* key = reinterpret_cast<unsigned long long*>(seg_smem) + (size_t)wave * CAP;
     uint16_t* val = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned long long*>(seg_smem) + (size_t)SEGS * CAP) + (size_t)wave * CAP;
-    const int64_t total = CLASS == 0 ? (int64_t)U : (int64_t)L.counts[CLASS - 1];
+    const int64_t total = CLASS == 0 ? (int64_t)(u_hi - u_lo) : (int64_t)L.counts[CLASS - 1];
     for (int64_t idx = (int64_t)blockIdx.x * SEGS + wave; idx < total; idx += (int64_t)gridDim.x * SEGS) {
-        const int32_t u = CLASS == 0 ? (int32_t)idx : (CLASS == 1 ? L.mid[idx] : L.longs[idx]);
+        const int32_t u = CLASS == 0 ? u_lo + (int32_t)idx : (CLASS == 1 ? L.mid[idx] : L.longs[idx]);
         const int64_t b = u_ptr[u], e = u_ptr[u + 1];
         const int64_t n64 = e - b;
         if (n64 > CAP) {  // (only class 0 meets these)
@@ -262,14 +266,147 @@ __global__ void __launch_bounds__(TPB) k_user_hash_order(const int64_t* __restri
         const int32_t user_raw = uid[u];
         for (int32_t i = tid; i < N; i += THREADS) {
             unsigned long long k = ~0ull;
-            if (i < n) k = ((unsigned long long)tuple_trie_key(user_raw, iid[s_col[b + i]]) << 32) | s_t[b + i];
+            if (i < n) {
+                if (FILE_ORDER) k = s_t[b + i];
+                else k = ((unsigned long long)tuple_trie_key(user_raw, iid[s_col[b + i]]) << 32) | s_t[b + i];
+            }
             key[i] = k;
             val[i] = (uint16_t)i;
         }
-        segment_bitonic<THREADS, BLOCK>(key, val, N, tid);
-        for (int32_t i = tid; i < n; i += THREADS) perm_uh[b + i] = (uint32_t)(b + val[i]);
+        segment_bitonic<THREADS, BLOCK, true>(key, val, N, tid);
+        for (int32_t i = tid; i < n; i += THREADS) perm_out[b + i] = (uint32_t)(b + val[i]);
         // (the next segment's stores into key / val follow this wave's / workgroup's reads in program order; the workgroup
         // form needs its barrier)
+        if (BLOCK) __syncthreads();
+    }
+}
+
+// ---- the canonical (user, item) order by a counting scatter + a sort of every user's own segment in LDS ---------------
+// As a global radix sort the canonical order is 5 passes over 20 M (64-bit key, value) pairs.  Dense user indices make the
+// first level a counting sort — one histogram, its prefix (= u_ptr), one scatter through per-user cursors, which leaves a
+// user's rows together but in no particular order — and a user's rows fit in LDS, where they are sorted by item (the same
+// three size classes as the hash order below).  A (user, item) pair is unique, so the result does not depend on the order
+// the scatter's atomics happened to run in; a duplicate pair shows up as two equal neighbours and sets ST_DUPLICATE.
+__global__ void k_count_users(int64_t n, const int32_t* __restrict__ du, uint32_t* __restrict__ cnt) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) atomicAdd(&cnt[du[t]], 1u);
+}
+static constexpr int SCAN_TILE = TPB * 8;
+// per tile of SCAN_TILE users: the number of their ratings; the longest row of all -> *max_len
+__global__ void __launch_bounds__(TPB) k_user_tile_sums(int32_t U, const uint32_t* __restrict__ cnt, uint32_t* __restrict__ tile_sum,
+                                                        uint32_t* __restrict__ max_len) {
+    __shared__ uint32_t ws[TPB / 64], wm[TPB / 64];
+    uint32_t s = 0, m = 0;
+    for (int j = 0; j < 8; ++j) {
+        const int64_t i = (int64_t)blockIdx.x * SCAN_TILE + j * TPB + threadIdx.x;
+        const uint32_t c = i < U ? cnt[i] : 0u;
+        s += c;
+        m = max(m, c);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o);
+        m = max(m, __shfl_xor(m, o));
+    }
+    if ((threadIdx.x & 63) == 0) { ws[threadIdx.x >> 6] = s; wm[threadIdx.x >> 6] = m; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < TPB / 64; ++w) { s += ws[w]; m = max(m, wm[w]); }
+        tile_sum[blockIdx.x] = s;
+        atomicMax(max_len, m);
+    }
+}
+// u_ptr = exclusive prefix of the counts; the counts are cleared on the way (they become the scatter's cursors)
+__global__ void __launch_bounds__(TPB) k_user_ptr(int32_t U, uint32_t* __restrict__ cnt, const uint32_t* __restrict__ tile_sum,
+                                                  int64_t* __restrict__ u_ptr) {
+    __shared__ unsigned long long wsum[TPB / 64];
+    __shared__ unsigned long long s_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long mine = 0;  // ratings of the users in the tiles before this one
+    for (int q = threadIdx.x; q < (int)blockIdx.x; q += TPB) mine += tile_sum[q];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if (lane == 0) wsum[wave] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long b = 0;
+        for (int w = 0; w < TPB / 64; ++w) b += wsum[w];
+        s_base = b;
+    }
+    __syncthreads();
+    const int64_t i0 = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * 8;  // 8 consecutive users per thread
+    uint32_t c[8], tot = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        c[j] = i0 + j < U ? cnt[i0 + j] : 0u;
+        tot += c[j];
+    }
+    const uint32_t incl = wave_incl_scan(tot);
+    __syncthreads();  // (wsum is reused)
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    unsigned long long run = s_base + incl - tot;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (i0 + j < U) {
+            u_ptr[i0 + j] = (int64_t)run;
+            cnt[i0 + j] = 0;
+        }
+        run += c[j];
+        if (i0 + j == (int64_t)U - 1) u_ptr[U] = (int64_t)run;
+    }
+}
+// row t goes to the next free slot of its user's segment, as (item << 32 | file row)
+__global__ void k_scatter_rows(int64_t n, const int32_t* __restrict__ du, const int32_t* __restrict__ di,
+                               const int64_t* __restrict__ u_ptr, uint32_t* __restrict__ cursor, unsigned long long* __restrict__ rows) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int32_t u = du[t];
+    const int64_t slot = u_ptr[u] + atomicAdd(&cursor[u], 1u);
+    rows[slot] = ((unsigned long long)(uint32_t)di[t] << 32) | (uint32_t)t;
+}
+template <int CLASS>
+__global__ void __launch_bounds__(TPB) k_user_item_order(const int64_t* __restrict__ u_ptr, int32_t U, SegLists L,
+                                                         const unsigned long long* __restrict__ rows, const double* __restrict__ rating,
+                                                         int32_t* __restrict__ s_user, int32_t* __restrict__ s_col,
+                                                         uint32_t* __restrict__ s_t, double* __restrict__ s_rating,
+                                                         uint32_t* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) char seg_smem[];
+    constexpr bool BLOCK = CLASS >= 1;
+    constexpr int CAP = CLASS == 0 ? SEG_SHORT_CAP : CLASS == 1 ? SEG_MID_CAP : SEG_BLOCK_CAP;
+    constexpr int THREADS = BLOCK ? TPB : 64;
+    constexpr int SEGS = BLOCK ? 1 : TPB / 64;
+    const int wave = BLOCK ? 0 : (int)(threadIdx.x >> 6);
+    const int tid = BLOCK ? (int)threadIdx.x : (int)(threadIdx.x & 63);
+    unsigned long long* key = reinterpret_cast<unsigned long long*>(seg_smem) + (size_t)wave * CAP;
+    const int64_t total = CLASS == 0 ? (int64_t)U : (int64_t)L.counts[CLASS - 1];
+    for (int64_t idx = (int64_t)blockIdx.x * SEGS + wave; idx < total; idx += (int64_t)gridDim.x * SEGS) {
+        const int32_t u = CLASS == 0 ? (int32_t)idx : (CLASS == 1 ? L.mid[idx] : L.longs[idx]);
+        const int64_t b = u_ptr[u], e = u_ptr[u + 1];
+        const int64_t n64 = e - b;
+        if (n64 > CAP) {  // (only class 0 meets these)
+            if (tid == 0) {
+                if (n64 <= SEG_MID_CAP) L.mid[atomicAdd(&L.counts[0], 1u)] = u;
+                else if (n64 <= SEG_BLOCK_CAP) L.longs[atomicAdd(&L.counts[1], 1u)] = u;
+                else atomicOr(status, (uint32_t)ST_LONG_ROW);
+            }
+            continue;
+        }
+        const int32_t n = (int32_t)n64;
+        int32_t N = 2;
+        while (N < n) N <<= 1;
+        for (int32_t i = tid; i < N; i += THREADS) key[i] = i < n ? rows[b + i] : ~0ull;
+        segment_bitonic<THREADS, BLOCK, false>(key, nullptr, N, tid);
+        for (int32_t i = tid; i < n; i += THREADS) {
+            const unsigned long long k = key[i];
+            const uint32_t t = (uint32_t)k;
+            s_user[b + i] = u;
+            s_col[b + i] = (int32_t)(k >> 32);
+            s_t[b + i] = t;
+            s_rating[b + i] = rating[t];
+            if (i > 0 && (key[i - 1] >> 32) == (k >> 32)) atomicOr(status, (uint32_t)ST_DUPLICATE);
+        }
         if (BLOCK) __syncthreads();
     }
 }
@@ -314,20 +451,6 @@ __global__ void k_unpack_positions(int64_t n, const uint64_t* __restrict__ key, 
     s_user[p] = (int32_t)(k >> lo_bits);
     s_col[p] = (int32_t)(k & ((1ull << lo_bits) - 1ull));
     if (p > 0 && key[p - 1] == k) atomicOr(status, (uint32_t)ST_DUPLICATE);
-}
-
-// ptr[s] = first index whose (key >> shift) >= s, s in [0, S]
-__global__ void k_segment_ptr(int64_t n, const uint64_t* __restrict__ sorted_key, int shift, int32_t S,
-                              int64_t* __restrict__ ptr) {
-    int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s > S) return;
-    int64_t lo = 0, hi = n;
-    while (lo < hi) {
-        int64_t mid = (lo + hi) >> 1;
-        if ((sorted_key[mid] >> shift) < (uint64_t)s) lo = mid + 1;
-        else hi = mid;
-    }
-    ptr[s] = lo;
 }
 
 __global__ void k_gather_f64(int64_t n, const uint32_t* __restrict__ idx, const double* __restrict__ src,
@@ -501,12 +624,6 @@ __global__ void k_preprocess(int64_t p0, int64_t p1, const int32_t* __restrict__
     s_pre[p] = (w != 0) ? s_dev[p] / w : 0.0;
 }
 
-static int bits_for(uint64_t max_value) {
-    int b = 1;
-    while (b < 64 && (max_value >> b) != 0) ++b;
-    return b;
-}
-
 template <bool SQUARE>
 static void fold(const int64_t* seg_ptr, int32_t lo, int32_t hi, const uint32_t* perm, const double* src,
                  double* out, hipStream_t st, int32_t spb = TPB) {
@@ -632,18 +749,15 @@ void prep_fit(Train& tr, PrepScratch& sc, int32_t shard_rank, int32_t shard_coun
     KN_HIP(hipGetLastError());
 
     const int ubits = bits_for(U), ibits = bits_for(I);
-    // canonical user-major order: sort file rows by (user, item)
     tr.s_user.alloc(n); tr.s_col.alloc(n); tr.s_t.alloc(n); tr.s_rating.alloc(n);
     tr.s_dev.alloc(n); tr.s_pre.alloc(n); tr.u_ptr.alloc(U + 1); tr.i_ptr.alloc(I + 1);
-    k_make_keys<<<nblocks(n), TPB, 0, st>>>(n, 0, sc.du_row.p, sc.di_row.p, tr.user_raw.p, tr.item_raw.p, sc.k64_a.p, ibits);
-    k_iota<<<nblocks(n), TPB, 0, st>>>(n, sc.v32_a.p);
-    KN_HIP(hipGetLastError());
-    sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.v32_a.p, tr.s_t.p, n, ibits + ubits, st);
-    k_unpack_positions<<<nblocks(n), TPB, 0, st>>>(n, sc.k64_b.p, tr.s_user.p, tr.s_col.p, sc.status.p, ibits);
-    k_segment_ptr<<<nblocks((int64_t)U + 1), TPB, 0, st>>>(n, sc.k64_b.p, ibits, tr.U, tr.u_ptr.p);
-    k_gather_f64<<<nblocks(n), TPB, 0, st>>>(n, tr.s_t.p, tr.rating.p, tr.s_rating.p);
-    sc.perm_f.ensure(n);
-    k_invert<<<nblocks(n), TPB, 0, st>>>(n, tr.s_t.p, sc.perm_f.p);
+    // row counts -> u_ptr, and the longest row: it decides between the per-user LDS sorts and the global radix sorts
+    const int32_t u_tiles = nblocks(U, SCAN_TILE);
+    sc.ucnt.ensure(U); sc.utile.ensure(u_tiles);
+    KN_HIP(hipMemsetAsync(sc.ucnt.p, 0, U * sizeof(uint32_t), st));
+    k_count_users<<<nblocks(n), TPB, 0, st>>>(n, sc.du_row.p, sc.ucnt.p);
+    k_user_tile_sums<<<u_tiles, TPB, 0, st>>>(tr.U, sc.ucnt.p, sc.utile.p, sc.status.p + 1);
+    k_user_ptr<<<u_tiles, TPB, 0, st>>>(tr.U, sc.ucnt.p, sc.utile.p, tr.u_ptr.p);
     KN_HIP(hipGetLastError());
 
     // owned block of users: ascending dense index, ceil(U / shards) each
@@ -652,66 +766,108 @@ void prep_fit(Train& tr, PrepScratch& sc, int32_t shard_rank, int32_t shard_coun
     tr.own_hi = std::min<int64_t>((int64_t)per * (shard_rank + 1), U);
     const int32_t lo = tr.own_lo, hi = tr.own_hi;
     int64_t p0 = 0, p1 = n;  // the owned users' positions in the canonical order
-    if (shard_count > 1) {
-        int64_t hp[2];
-        KN_HIP(hipMemcpyAsync(&hp[0], tr.u_ptr.p + lo, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-        KN_HIP(hipMemcpyAsync(&hp[1], tr.u_ptr.p + hi, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    uint32_t max_len = 0;
+    {
+        int64_t hp[2] = {0, n};
+        KN_HIP(hipMemcpyAsync(&max_len, sc.status.p + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        if (shard_count > 1) {
+            KN_HIP(hipMemcpyAsync(&hp[0], tr.u_ptr.p + lo, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+            KN_HIP(hipMemcpyAsync(&hp[1], tr.u_ptr.p + hi, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        }
         KN_HIP(hipStreamSynchronize(st));
         p0 = hp[0];
         p1 = hp[1];
     }
+    // (KNNCF_DEBUG_GLOBAL_HASH_ORDER: test hook, forces the global sorts that a user with more than SEG_BLOCK_CAP ratings takes)
+    const bool seg_sorts = max_len <= (uint32_t)SEG_BLOCK_CAP && !getenv("KNNCF_DEBUG_GLOBAL_HASH_ORDER");
+    sc.long_rows.ensure(2 * (size_t)U + 2);
+    SegLists L{sc.long_rows.p, sc.long_rows.p + U + 1, sc.status.p + 2};
+    constexpr size_t smem_pair0 = (size_t)(TPB / 64) * SEG_SHORT_CAP * 10, smem_pair1 = (size_t)SEG_MID_CAP * 10, smem_pair2 = (size_t)SEG_BLOCK_CAP * 10;
+    constexpr size_t smem_key0 = (size_t)(TPB / 64) * SEG_SHORT_CAP * 8, smem_key1 = (size_t)SEG_MID_CAP * 8, smem_key2 = (size_t)SEG_BLOCK_CAP * 8;
 
-    // fold orders: stable sorts of the file-order sequence of positions
+    // canonical user-major order: file rows by (user, item)
+    bool have_perm_f = false;
+    auto need_perm_f = [&] {  // position of every file row: the value sequence of the global fold-order sorts
+        if (have_perm_f) return;
+        sc.perm_f.ensure(n);
+        k_invert<<<nblocks(n), TPB, 0, st>>>(n, tr.s_t.p, sc.perm_f.p);
+        have_perm_f = true;
+    };
+    if (seg_sorts) {
+        k_scatter_rows<<<nblocks(n), TPB, 0, st>>>(n, sc.du_row.p, sc.di_row.p, tr.u_ptr.p, sc.ucnt.p,
+                                                   reinterpret_cast<unsigned long long*>(sc.k64_a.p));
+        KN_HIP(hipMemsetAsync(sc.status.p + 2, 0, 2 * sizeof(uint32_t), st));  // (words 2, 3: the two list lengths)
+        static PerDeviceState lds2;
+        ensure_dynamic_lds(lds2, (const void*)k_user_item_order<2>, smem_key2);
+        const unsigned long long* rows = reinterpret_cast<const unsigned long long*>(sc.k64_a.p);
+        k_user_item_order<0><<<nblocks(U, TPB / 64), TPB, smem_key0, st>>>(tr.u_ptr.p, tr.U, L, rows, tr.rating.p, tr.s_user.p, tr.s_col.p, tr.s_t.p, tr.s_rating.p, sc.status.p);
+        k_user_item_order<1><<<2048, TPB, smem_key1, st>>>(tr.u_ptr.p, tr.U, L, rows, tr.rating.p, tr.s_user.p, tr.s_col.p, tr.s_t.p, tr.s_rating.p, sc.status.p);
+        k_user_item_order<2><<<256, TPB, smem_key2, st>>>(tr.u_ptr.p, tr.U, L, rows, tr.rating.p, tr.s_user.p, tr.s_col.p, tr.s_t.p, tr.s_rating.p, sc.status.p);
+    } else {
+        k_make_keys<<<nblocks(n), TPB, 0, st>>>(n, 0, sc.du_row.p, sc.di_row.p, tr.user_raw.p, tr.item_raw.p, sc.k64_a.p, ibits);
+        k_iota<<<nblocks(n), TPB, 0, st>>>(n, sc.v32_a.p);
+        KN_HIP(hipGetLastError());
+        sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.v32_a.p, tr.s_t.p, n, ibits + ubits, st);
+        k_unpack_positions<<<nblocks(n), TPB, 0, st>>>(n, sc.k64_b.p, tr.s_user.p, tr.s_col.p, sc.status.p, ibits);
+        k_gather_f64<<<nblocks(n), TPB, 0, st>>>(n, tr.s_t.p, tr.rating.p, tr.s_rating.p);
+    }
+    KN_HIP(hipGetLastError());
+
+    // fold orders: the positions of every owned user re-ordered inside the user's segment
     // (the item-side fold orders belong to K4, which only the baseline predictors use: prep_item_stats)
     // usersAvg :113 sums a user's ratings in file order; dyadic ratings (every MovieLens file) sum exactly in ANY order, so a
     // whole-file fit then folds them in the canonical order and never builds the (user, file row) order
     const bool need_uf = !dyadic || n <= 4 || shard_count > 1;
     if (need_uf) tr.perm_uf.alloc(n);
     else tr.perm_uf.release();
-    if (shard_count == 1) {
+    if (n > 4) tr.perm_uh.alloc(n);  // a Map of <= 4 entries (Map1..Map4) iterates in insertion = file order (N4)
+    else tr.perm_uh.release();
+    if (seg_sorts && hi > lo) {
+        // every owned user's segment sorted in LDS (three size classes), by file row and by (trie key of the tuple hash, file row)
+        static PerDeviceState lds1h, lds2h, lds1f, lds2f;
+        ensure_dynamic_lds(lds1h, (const void*)k_user_hash_order<1, false>, smem_pair1);
+        ensure_dynamic_lds(lds2h, (const void*)k_user_hash_order<2, false>, smem_pair2);
+        ensure_dynamic_lds(lds1f, (const void*)k_user_hash_order<1, true>, smem_pair1);
+        ensure_dynamic_lds(lds2f, (const void*)k_user_hash_order<2, true>, smem_pair2);
+        if (need_uf) {
+            KN_HIP(hipMemsetAsync(sc.status.p + 2, 0, 2 * sizeof(uint32_t), st));
+            k_user_hash_order<0, true><<<nblocks(hi - lo, TPB / 64), TPB, smem_pair0, st>>>(tr.u_ptr.p, lo, hi, L, tr.uid.p, tr.iid.p, tr.s_col.p, tr.s_t.p, tr.perm_uf.p, sc.status.p);
+            k_user_hash_order<1, true><<<2048, TPB, smem_pair1, st>>>(tr.u_ptr.p, lo, hi, L, tr.uid.p, tr.iid.p, tr.s_col.p, tr.s_t.p, tr.perm_uf.p, sc.status.p);
+            k_user_hash_order<2, true><<<256, TPB, smem_pair2, st>>>(tr.u_ptr.p, lo, hi, L, tr.uid.p, tr.iid.p, tr.s_col.p, tr.s_t.p, tr.perm_uf.p, sc.status.p);
+        }
+        if (n > 4) {
+            KN_HIP(hipMemsetAsync(sc.status.p + 2, 0, 2 * sizeof(uint32_t), st));
+            k_user_hash_order<0, false><<<nblocks(hi - lo, TPB / 64), TPB, smem_pair0, st>>>(tr.u_ptr.p, lo, hi, L, tr.uid.p, tr.iid.p, tr.s_col.p, tr.s_t.p, tr.perm_uh.p, sc.status.p);
+            k_user_hash_order<1, false><<<2048, TPB, smem_pair1, st>>>(tr.u_ptr.p, lo, hi, L, tr.uid.p, tr.iid.p, tr.s_col.p, tr.s_t.p, tr.perm_uh.p, sc.status.p);
+            k_user_hash_order<2, false><<<256, TPB, smem_pair2, st>>>(tr.u_ptr.p, lo, hi, L, tr.uid.p, tr.iid.p, tr.s_col.p, tr.s_t.p, tr.perm_uh.p, sc.status.p);
+        }
+    } else if (!seg_sorts && shard_count == 1) {  // stable global sorts of the file-order sequence of positions
+        need_perm_f();
         if (need_uf) {
             k_copy_keys_u32<<<nblocks(n), TPB, 0, st>>>(n, sc.du_row.p, sc.k32_a.p);
             sort_pairs_u32_u32(sc.sort, sc.k32_a.p, sc.k32_b.p, sc.perm_f.p, tr.perm_uf.p, n, ubits, st);
         }
-    } else if (p1 > p0) {
+        if (n > 4) {
+            k_make_keys<<<nblocks(n), TPB, 0, st>>>(n, 2, sc.du_row.p, sc.di_row.p, tr.user_raw.p, tr.item_raw.p, sc.k64_a.p, 32);
+            sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.perm_f.p, tr.perm_uh.p, n, 32 + ubits, st);
+        }
+    } else if (!seg_sorts && p1 > p0) {
         // A shard folds its own users only (K2, K3 below), so it orders only their positions: the slice [p0, p1) of the
-        // canonical order by (user, file row) — the same segments the whole-file sort yields, 1/shards of the work.
+        // canonical order by (user, file row) — the same segments the whole-file sort yields, 1/shards of the work —
+        // and that sequence, stably re-sorted by (user, trie key)
         const int tbits = bits_for((uint64_t)n);
         k_slice_file_keys<<<nblocks(p1 - p0), TPB, 0, st>>>(p0, p1 - p0, lo, tr.s_user.p, tr.s_t.p, tbits, sc.k64_a.p, sc.v32_a.p);
         KN_HIP(hipGetLastError());
         sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.v32_a.p, tr.perm_uf.p + p0, p1 - p0, tbits + bits_for((uint64_t)(hi - lo)), st);
-    }
-    KN_HIP(hipGetLastError());
-    bool segment_sorted = false;
-    if (n > 4) {  // a Map of <= 4 entries (Map1..Map4) iterates in insertion = file order (N4)
-        tr.perm_uh.alloc(n);
-        if (shard_count == 1 && !getenv("KNNCF_DEBUG_GLOBAL_HASH_ORDER")) {
-            // every user's segment sorted in LDS (three size classes; a segment beyond the last one -> ST_LONG_ROW, below)
-            sc.long_rows.ensure(2 * (size_t)U + 2);
-            KN_HIP(hipMemsetAsync(sc.status.p + 2, 0, 2 * sizeof(uint32_t), st));  // (words 2, 3: the two list lengths)
-            SegLists L{sc.long_rows.p, sc.long_rows.p + U + 1, sc.status.p + 2};
-            static PerDeviceState lds1, lds2;
-            const size_t smem0 = (size_t)(TPB / 64) * SEG_SHORT_CAP * 10, smem1 = (size_t)SEG_MID_CAP * 10, smem2 = (size_t)SEG_BLOCK_CAP * 10;
-            ensure_dynamic_lds(lds1, (const void*)k_user_hash_order<1>, smem1);
-            ensure_dynamic_lds(lds2, (const void*)k_user_hash_order<2>, smem2);
-            k_user_hash_order<0><<<nblocks(U, TPB / 64), TPB, smem0, st>>>(tr.u_ptr.p, tr.U, L, tr.uid.p, tr.iid.p, tr.s_col.p, tr.s_t.p, tr.perm_uh.p, sc.status.p);
-            k_user_hash_order<1><<<2048, TPB, smem1, st>>>(tr.u_ptr.p, tr.U, L, tr.uid.p, tr.iid.p, tr.s_col.p, tr.s_t.p, tr.perm_uh.p, sc.status.p);
-            k_user_hash_order<2><<<256, TPB, smem2, st>>>(tr.u_ptr.p, tr.U, L, tr.uid.p, tr.iid.p, tr.s_col.p, tr.s_t.p, tr.perm_uh.p, sc.status.p);
-            KN_HIP(hipGetLastError());
-            segment_sorted = true;
-        } else if (shard_count == 1) {
-            k_make_keys<<<nblocks(n), TPB, 0, st>>>(n, 2, sc.du_row.p, sc.di_row.p, tr.user_raw.p, tr.item_raw.p, sc.k64_a.p, 32);
-            sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.perm_f.p, tr.perm_uh.p, n, 32 + ubits, st);
-        } else if (p1 > p0) {  // the slice in (user, file row) order, stably re-sorted by (user, trie key)
+        if (n > 4) {
             k_slice_hash_keys<<<nblocks(p1 - p0), TPB, 0, st>>>(p1 - p0, lo, tr.perm_uf.p + p0, tr.s_user.p, tr.s_t.p, tr.user_raw.p,
                                                                tr.item_raw.p, sc.k64_a.p);
             KN_HIP(hipGetLastError());
             sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, tr.perm_uf.p + p0, tr.perm_uh.p + p0, p1 - p0,
                                32 + bits_for((uint64_t)(hi - lo)), st);
         }
-    } else {
-        tr.perm_uh.release();
     }
+    KN_HIP(hipGetLastError());
     tr.item_stats_ready = false;
 
     // K1: average :94 — left fold over the file; exact in any order for dyadic ratings
@@ -719,10 +875,7 @@ void prep_fit(Train& tr, PrepScratch& sc, int32_t shard_rank, int32_t shard_coun
     KN_HIP(hipGetLastError());
     uint32_t status = read_status(sc, st);
     KN_REQUIRE(!(status & ST_DUPLICATE), KNNCF_E_DUPLICATE, "fit: duplicate (user,item) training rows");
-    if (segment_sorted && (status & ST_LONG_ROW)) {  // a user with more ratings than a workgroup sorts in LDS: the global sort
-        k_make_keys<<<nblocks(n), TPB, 0, st>>>(n, 2, sc.du_row.p, sc.di_row.p, tr.user_raw.p, tr.item_raw.p, sc.k64_a.p, 32);
-        sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.perm_f.p, tr.perm_uh.p, n, 32 + ubits, st);
-    }
+    KN_REQUIRE(!(status & ST_LONG_ROW), KNNCF_E_STATE, "fit: a row longer than the segment sorts take reached them");
     // The summation order of a pair with a <= 4-rating user follows the memo history of the reference's closures; a single
     // handle models it (nbr_seq), but the shards do not exchange their build sequence numbers: refused rather than
     // answered differently from the single-GPU run.  Every rank holds all rows, so every rank refuses alike.
@@ -882,11 +1035,12 @@ __global__ void k_col_keys(int64_t n, const int32_t* __restrict__ s_col, uint32_
     val[p] = (uint32_t)p;
 }
 
-// key = ~count so that an ascending stable sort lists the most-rated items first (ties: dense order)
-__global__ void k_pop_keys(int32_t I, const int64_t* __restrict__ i_ptr, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
+// key = U - count (an item has at most U raters) so that an ascending stable sort lists the most-rated items first (ties:
+// dense order) on bits_for(U) key bits
+__global__ void k_pop_keys(int32_t I, int32_t U, const int64_t* __restrict__ i_ptr, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
     int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= I) return;
-    key[i] = ~(uint64_t)(i_ptr[i + 1] - i_ptr[i]);
+    key[i] = (uint64_t)U - (uint64_t)(i_ptr[i + 1] - i_ptr[i]);
     val[i] = (uint32_t)i;
 }
 
@@ -928,15 +1082,15 @@ void prep_commit(Train& tr, PrepScratch& sc, hipStream_t st) {
             tr.ib_words = 0;
         }
     }
-    k_pop_keys<<<nblocks(I), TPB, 0, st>>>(I, tr.i_ptr.p, sc.k64_a.p, sc.v32_a.p);
+    k_pop_keys<<<nblocks(I), TPB, 0, st>>>(I, tr.U, tr.i_ptr.p, sc.k64_a.p, sc.v32_a.p);
     KN_HIP(hipGetLastError());
-    sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.v32_a.p, reinterpret_cast<uint32_t*>(tr.pop_item.p), I, 64, st);
+    sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.v32_a.p, reinterpret_cast<uint32_t*>(tr.pop_item.p), I, bits_for((uint64_t)tr.U), st);
     {
         std::vector<uint64_t> hk(I);
         KN_HIP(hipMemcpyAsync(hk.data(), sc.k64_b.p, (size_t)I * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         KN_HIP(hipStreamSynchronize(st));
         tr.pop_count.resize(I);
-        for (int32_t i = 0; i < I; ++i) tr.pop_count[i] = (int64_t)~hk[i];
+        for (int32_t i = 0; i < I; ++i) tr.pop_count[i] = (int64_t)tr.U - (int64_t)hk[i];
     }
     KN_HIP(hipGetLastError());
 }

@@ -3,7 +3,7 @@
 //
 // One pass = three launches over tiles of TILE = 256 threads x ITEMS keys:
 //   k_radix_hist      per-tile digit counts                      -> table[tile][256]
-//   k_radix_scan      per digit, exclusive prefix along the tiles -> table (in place) + total[256]
+//   k_radix_scan      per digit, exclusive prefix along the tiles -> table (in place) + total[256]   (skipped for <= 64 tiles)
 //   k_radix_scatter   ranks the tile's keys (stable), re-orders them in LDS so that every digit's keys leave as one
 //                     contiguous run, writes them at digit base + tile prefix + rank
 // The in-tile rank is wave64 work: the lanes of a wave that hold the same digit find each other with 8 ballots (one per
@@ -22,6 +22,7 @@ constexpr int RS_BITS = 8;
 constexpr int RS_BINS = 1 << RS_BITS;
 constexpr int RS_THREADS = 256;
 constexpr int RS_WAVES = RS_THREADS / 64;
+constexpr int RS_SELF_SCAN_TILES = 64;
 
 template <class K>
 struct RsTile {
@@ -86,11 +87,13 @@ __global__ void __launch_bounds__(1024) k_radix_scan(uint32_t* __restrict__ tabl
     }
 }
 
-template <class K, bool VALUES>
+// SELF_SCAN (few tiles): `table` still holds the tiles' raw counts and every workgroup sums the rows before its own itself —
+// the scan launch (12 us of mostly latency) is skipped
+template <class K, bool VALUES, bool SELF_SCAN>
 __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const K* __restrict__ kin, K* __restrict__ kout,
                                                               const uint32_t* __restrict__ vin, uint32_t* __restrict__ vout, int64_t n,
                                                               int shift, uint32_t mask, const uint32_t* __restrict__ table,
-                                                              const uint32_t* __restrict__ total) {
+                                                              const uint32_t* __restrict__ total, int32_t n_tiles) {
     constexpr int ITEMS = RsTile<K>::ITEMS, TILE = RsTile<K>::TILE;
     __shared__ K s_key[TILE];
     __shared__ uint32_t s_val[VALUES ? TILE : 1];
@@ -144,7 +147,19 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const K* __restric
         const uint32_t incl = wave_incl_scan(tot);
         if (lane == 63) s_wsum[wave] = incl;
         // digit bases over the whole array: exclusive prefix of total[]
-        const uint32_t g = total[d];
+        uint32_t g, before;
+        if (SELF_SCAN) {
+            g = 0;
+            before = 0;
+            for (int32_t t = 0; t < n_tiles; ++t) {
+                const uint32_t ct = table[(int64_t)t * RS_BINS + d];
+                if (t < (int32_t)blockIdx.x) before += ct;
+                g += ct;
+            }
+        } else {
+            g = total[d];
+            before = table[(int64_t)blockIdx.x * RS_BINS + d];
+        }
         const uint32_t gincl = wave_incl_scan(g);
         __shared__ uint32_t s_gsum[RS_WAVES];
         if (lane == 63) s_gsum[wave] = gincl;
@@ -155,7 +170,7 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const K* __restric
             if (w < wave) { off += s_wsum[w]; goff += s_gsum[w]; }
         const uint32_t start = off + incl - tot;
         s_start[d] = start;
-        s_gofs[d] = (goff + gincl - g) + table[(int64_t)blockIdx.x * RS_BINS + d] - start;
+        s_gofs[d] = (goff + gincl - g) + before - start;
     }
     __syncthreads();
 #pragma unroll
@@ -213,8 +228,12 @@ void radix_sort(SortWorkspace& ws, const K* kin, K* kout, const uint32_t* vin, u
         K* dst_k = to_out ? kout : ktmp;
         uint32_t* dst_v = to_out ? vout : vtmp;
         k_radix_hist<K><<<(unsigned)n_tiles, RS_THREADS, 0, st>>>(src_k, (int64_t)n, shift, mask, table);
-        k_radix_scan<<<RS_BINS / 16, 1024, 0, st>>>(table, n_tiles, total);
-        k_radix_scatter<K, VALUES><<<(unsigned)n_tiles, RS_THREADS, 0, st>>>(src_k, dst_k, src_v, dst_v, (int64_t)n, shift, mask, table, total);
+        if (n_tiles <= RS_SELF_SCAN_TILES) {
+            k_radix_scatter<K, VALUES, true><<<(unsigned)n_tiles, RS_THREADS, 0, st>>>(src_k, dst_k, src_v, dst_v, (int64_t)n, shift, mask, table, total, (int32_t)n_tiles);
+        } else {
+            k_radix_scan<<<RS_BINS / 16, 1024, 0, st>>>(table, n_tiles, total);
+            k_radix_scatter<K, VALUES, false><<<(unsigned)n_tiles, RS_THREADS, 0, st>>>(src_k, dst_k, src_v, dst_v, (int64_t)n, shift, mask, table, total, (int32_t)n_tiles);
+        }
         KN_HIP(hipGetLastError());
         src_k = dst_k;
         src_v = dst_v;

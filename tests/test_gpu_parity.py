@@ -352,10 +352,18 @@ def test_several_row_blocks_and_the_overlap_flag(kn, oracle, syn100k, flags, sym
     e.close()
 
 
-def test_two_shards_on_one_gpu_equal_single_engine(kn, pkg, oracle, synth):
+@pytest.mark.parametrize("global_sorts", [False, True])
+def test_two_shards_on_one_gpu_equal_single_engine(kn, pkg, oracle, synth, monkeypatch, global_sorts):
     """The C-ABI shard protocol (view -> exchange -> commit -> partial MAE) with two handles in one
-    process; the exchange that RCCL's all-gather performs between GPUs is done here by device copies."""
+    process; the exchange that RCCL's all-gather performs between GPUs is done here by device copies.
+    Once with every shard ordering its users' positions by per-user LDS sorts, once by the global (slice) radix sorts that
+    a file with a very long row takes."""
     import torch
+
+    if global_sorts:
+        monkeypatch.setenv("KNNCF_DEBUG_GLOBAL_HASH_ORDER", "1")
+    else:
+        monkeypatch.delenv("KNNCF_DEBUG_GLOBAL_HASH_ORDER", raising=False)
 
     sharded = importlib.import_module(pkg.__name__ + ".sharded")
     d = synth.syn_scaled(700, 400, 42_000, seed=11, half_stars=True, shuffle=True)
@@ -451,31 +459,36 @@ def test_ids_outside_the_direct_tables(kn, oracle, synth, monkeypatch):
 
 
 def test_user_rows_of_every_size_class(kn, oracle, monkeypatch):
-    """the (user, HashMap order) positions come from per-user LDS sorts in three size classes (<= 512, <= 2048, <= 8192
-    ratings) and from the global radix sort when a user has more: users of 9 000, 3 000, 1 000 and ~60 ratings in one file;
-    the norms (hence every similarity, bit for bit) depend on that order.  Also with the global sort forced for everyone,
+    """the canonical (user, item) order and the (user, HashMap order) / (user, file row) positions come from per-user LDS
+    sorts in three size classes (<= 512, <= 2048, <= 8192 ratings) and from the global radix sorts when some user has more:
+    files with users of 3 000, 1 000 and ~60 ratings, with and without one of 12 000 (10 800 of them in the training part);
+    the norms (hence every similarity, bit for bit) depend on those orders.  Also with the global sorts forced,
     and with non-dyadic ratings (then usersAvg really folds in file order)."""
-    rng = np.random.default_rng(11)
-    n_items = 10_000
-    users, items = [], []
-    for u, cnt in [(1, 9_000), (2, 3_000), (3, 1_000)] + [(10 + j, int(rng.integers(30, 90))) for j in range(40)]:
-        its = rng.choice(n_items, size=cnt, replace=False) + 1
-        users += [u] * cnt
-        items += its.tolist()
-    users, items = np.asarray(users, np.int32), np.asarray(items, np.int32)
-    order = rng.permutation(len(users))
-    users, items = users[order], items[order]
-    for dyadic in (True, False):
-        ratings = rng.integers(1, 11, size=len(users)) / 2.0
-        if not dyadic:
-            ratings = ratings + rng.integers(0, 7, size=len(users)) * 0.1  # (sums now depend on the order)
-            ratings = np.minimum(ratings, 5.0)
+    for big, variants in ((7_000, ((True, False), (True, True), (False, False), (False, True))), (12_000, ((True, False), (False, False)))):
+        rng = np.random.default_rng(11)
+        n_items = 20_000
+        users, items = [], []
+        for u, cnt in [(1, big), (2, 3_000), (3, 1_000)] + [(10 + j, int(rng.integers(30, 90))) for j in range(40)]:
+            its = rng.choice(n_items, size=cnt, replace=False) + 1
+            users += [u] * cnt
+            items += its.tolist()
+        users, items = np.asarray(users, np.int32), np.asarray(items, np.int32)
+        order = rng.permutation(len(users))
+        users, items = users[order], items[order]
         cut = len(users) * 9 // 10
-        tr = (users[:cut], items[:cut], ratings[:cut])
-        te = (users[cut:], items[cut:], ratings[cut:])
-        p = oracle.Model(*tr).pipeline(oracle.SIM_COSINE, 10)
-        want, preds = p.mae(*te, True)
-        for forced in (False, True):
+        assert (np.sum(users[:cut] == 1) > 8192) == (big > 10_000)  # (the heaviest row is beyond the last LDS class or inside it)
+        made = {}
+        for dyadic, forced in variants:
+            if dyadic not in made:
+                ratings = rng.integers(1, 11, size=len(users)) / 2.0
+                if not dyadic:
+                    ratings = ratings + rng.integers(0, 7, size=len(users)) * 0.1  # (sums now depend on the order)
+                    ratings = np.minimum(ratings, 5.0)
+                tr = (users[:cut], items[:cut], ratings[:cut])
+                te = (users[cut:], items[cut:], ratings[cut:])
+                p = oracle.Model(*tr).pipeline(oracle.SIM_COSINE, 10)
+                made[dyadic] = (tr, te) + p.mae(*te, True)
+            tr, te, want, preds = made[dyadic]
             if forced:
                 monkeypatch.setenv("KNNCF_DEBUG_GLOBAL_HASH_ORDER", "1")
             else:
