@@ -103,7 +103,15 @@ struct PrepScratch {
     DArr<int32_t> long_rows;  // [2 (U + 1)] users whose segment is sorted by the wider classes of k_user_hash_order
     DArr<double> dsum;      // small reduction scratch
     DArr<uint4> rec;        // [2 n] (preprocessed rating, deviation | user, file row) records: one 32-byte gather per entry
+    // second stream of the fit: the per-user LDS sorts of the few long rows run beside those of everybody else
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    void ensure_aux();
     void release_all();
+    PrepScratch() = default;
+    PrepScratch(const PrepScratch&) = delete;
+    PrepScratch& operator=(const PrepScratch&) = delete;
+    ~PrepScratch();
 };
 
 // K0 + K1 + owned part of K2/K3.  Throws Error on invalid data.

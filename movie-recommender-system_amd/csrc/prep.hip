@@ -19,6 +19,18 @@ namespace knncf {
 static constexpr int TPB = 256;
 static inline int nblocks(int64_t n, int per = TPB) { return (int)std::max<int64_t>(1, ceil_div(n, per)); }
 
+void PrepScratch::ensure_aux() {
+    if (aux) return;
+    KN_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+    KN_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    KN_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+}
+PrepScratch::~PrepScratch() {
+    if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); }
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+}
+
 void PrepScratch::release_all() {
     sort.tmp.release();
     k64_a.release(); k64_b.release(); v32_a.release(); v32_b.release();
@@ -192,19 +204,23 @@ static constexpr int SEG_MID_CAP = 2048;     // class 1: one workgroup per segme
 static constexpr int SEG_BLOCK_CAP = 8192;   // class 2: one workgroup per segment of the long list (80 KB)
 // (powers of two: a segment is padded to the next one for the network)
 
+// The network's stages with a stride of at most 64 pair elements inside one 128-element chunk, and the chunk of pair index t
+// belongs to the wave that t's 64-group maps to (THREADS is a multiple of 64): those stages need no workgroup barrier, only
+// the wave's own ordering.  A workgroup barrier is due before a stage whose pairs cross chunks and before the first
+// wave-local stage after one (27 of the 91 stages of an 8192-element segment instead of all of them).
 template <int THREADS, bool BLOCK, bool VAL>
 __device__ __forceinline__ void segment_bitonic(unsigned long long* key, uint16_t* val, int32_t N, int tid) {
-    auto sync = [] {
-        if (BLOCK) {
-            __syncthreads();
-        } else {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     };
+    bool prev_wide = true;  // (the segment was loaded by arbitrary threads)
     for (int32_t size = 2; size <= N; size <<= 1) {
         for (int32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            sync();
+            const bool wide = stride >= 128;
+            if (BLOCK && (wide || prev_wide)) __syncthreads();
+            else wave_sync();
+            prev_wide = wide;
             for (int32_t t = tid; t < (N >> 1); t += THREADS) {
                 const int32_t lo = 2 * t - (t & (stride - 1));
                 const int32_t hi = lo + stride;
@@ -220,7 +236,8 @@ __device__ __forceinline__ void segment_bitonic(unsigned long long* key, uint16_
             }
         }
     }
-    sync();
+    if (BLOCK) __syncthreads();
+    else wave_sync();
 }
 
 struct SegLists {
@@ -229,19 +246,32 @@ struct SegLists {
     uint32_t* counts;    // [0] = |mid|, [1] = |longs|
 };
 
-// CLASS 0 walks the users [u_lo, u_hi) (one wave each) and files the longer segments into the two lists; CLASS 1 / 2 walk
-// their list (a workgroup per entry, grid-stride: the list's length stays on the device).  The host only takes this path
-// when no segment exceeds SEG_BLOCK_CAP (prep_fit reads the longest row's length back); ST_LONG_ROW is a consistency check.
+// users beyond the one-wave class, filed by size class (one thread per user; the order inside a list carries no meaning)
+__global__ void k_classify_rows(int32_t U, const int64_t* __restrict__ u_ptr, SegLists L) {
+    const int32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= U) return;
+    const int64_t n = u_ptr[u + 1] - u_ptr[u];
+    if (n > SEG_SHORT_CAP && n <= SEG_MID_CAP) L.mid[atomicAdd(&L.counts[0], 1u)] = u;
+    else if (n > SEG_MID_CAP && n <= SEG_BLOCK_CAP) L.longs[atomicAdd(&L.counts[1], 1u)] = u;
+}
+static constexpr int seg_threads(int cls) { return cls == 2 ? 512 : TPB; }
+
+// CLASS 0 walks the users [u_lo, u_hi) (one wave each, skipping the longer segments); CLASS 1 / 2 walk their list
+// (k_classify_rows; a workgroup per entry, grid-stride: the list's length stays on the device) and keep to the same user
+// range.  The three classes touch disjoint users, so prep_fit runs the two list classes on a second stream beside class 0:
+// a segment of 8192 is one workgroup's chain of 91 barrier-separated network stages, 0.2 ms during which it needs no CU
+// but its own.  The host only takes this path when no segment exceeds SEG_BLOCK_CAP (prep_fit reads the longest row's
+// length back); ST_LONG_ROW is a consistency check.
 // FILE_ORDER: the key is the file row alone — perm_uf, the (user, file row) order of usersAvg :113.
 template <int CLASS, bool FILE_ORDER>
-__global__ void __launch_bounds__(TPB) k_user_hash_order(const int64_t* __restrict__ u_ptr, int32_t u_lo, int32_t u_hi, SegLists L,
+__global__ void __launch_bounds__(seg_threads(CLASS)) k_user_hash_order(const int64_t* __restrict__ u_ptr, int32_t u_lo, int32_t u_hi, SegLists L,
                                                          const int32_t* __restrict__ uid, const int32_t* __restrict__ iid,
                                                          const int32_t* __restrict__ s_col, const uint32_t* __restrict__ s_t,
                                                          uint32_t* __restrict__ perm_out, uint32_t* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) char seg_smem[];
     constexpr bool BLOCK = CLASS >= 1;
     constexpr int CAP = CLASS == 0 ? SEG_SHORT_CAP : CLASS == 1 ? SEG_MID_CAP : SEG_BLOCK_CAP;
-    constexpr int THREADS = BLOCK ? TPB : 64;
+    constexpr int THREADS = BLOCK ? seg_threads(CLASS) : 64;
     constexpr int SEGS = BLOCK ? 1 : TPB / 64;  // segments in flight per workgroup
     const int wave = BLOCK ? 0 : (int)(threadIdx.x >> 6);
     const int tid = BLOCK ? (int)threadIdx.x : (int)(threadIdx.x & 63);
@@ -250,14 +280,11 @@ __global__ void __launch_bounds__(TPB) k_user_hash_order(const int64_t* __restri
     const int64_t total = CLASS == 0 ? (int64_t)(u_hi - u_lo) : (int64_t)L.counts[CLASS - 1];
     for (int64_t idx = (int64_t)blockIdx.x * SEGS + wave; idx < total; idx += (int64_t)gridDim.x * SEGS) {
         const int32_t u = CLASS == 0 ? u_lo + (int32_t)idx : (CLASS == 1 ? L.mid[idx] : L.longs[idx]);
+        if (CLASS > 0 && (u < u_lo || u >= u_hi)) continue;  // (workgroup-uniform)
         const int64_t b = u_ptr[u], e = u_ptr[u + 1];
         const int64_t n64 = e - b;
-        if (n64 > CAP) {  // (only class 0 meets these)
-            if (tid == 0) {
-                if (n64 <= SEG_MID_CAP) L.mid[atomicAdd(&L.counts[0], 1u)] = u;
-                else if (n64 <= SEG_BLOCK_CAP) L.longs[atomicAdd(&L.counts[1], 1u)] = u;
-                else atomicOr(status, (uint32_t)ST_LONG_ROW);
-            }
+        if (n64 > CAP) {  // (only class 0 meets these: they are on the lists)
+            if (n64 > SEG_BLOCK_CAP && tid == 0) atomicOr(status, (uint32_t)ST_LONG_ROW);
             continue;
         }
         const int32_t n = (int32_t)n64;
@@ -287,9 +314,35 @@ __global__ void __launch_bounds__(TPB) k_user_hash_order(const int64_t* __restri
 // user's rows together but in no particular order — and a user's rows fit in LDS, where they are sorted by item (the same
 // three size classes as the hash order below).  A (user, item) pair is unique, so the result does not depend on the order
 // the scatter's atomics happened to run in; a duplicate pair shows up as two equal neighbours and sets ST_DUPLICATE.
+// Rating files are usually grouped by user (every MovieLens file is), so the lanes of a wave mostly hold ONE user: 20 M
+// atomics of which 64 in a row hit the same address serialise in the L2 (measured: 1.3 ms for the count, 1.8 ms for the
+// scatter).  A wave therefore aggregates its RUNS of equal users — a lane that differs from the lane below starts a run and
+// issues one atomic for the run's length; equal users that are not neighbours simply make two runs.
+struct WaveRun {
+    int head_lane;  // first lane of this lane's run
+    int len;        // length of the run (meaningful on the head lane)
+    bool head;
+};
+__device__ __forceinline__ WaveRun wave_runs(int32_t u, bool valid) {
+    const int lane = threadIdx.x & 63;
+    const int32_t below = __shfl_up(u, 1);
+    const unsigned long long vmask = __ballot(valid);
+    WaveRun r;
+    r.head = valid && (lane == 0 || below != u);
+    const unsigned long long heads = __ballot(r.head);
+    const unsigned long long upto = heads & ((2ull << lane) - 1ull);            // heads at or below this lane
+    r.head_lane = upto ? 63 - __clzll((long long)upto) : 0;
+    const unsigned long long above = lane == 63 ? 0ull : heads & ~((2ull << lane) - 1ull);  // heads above this lane
+    const int n_valid = __popcll(vmask);                                          // (the valid lanes are a prefix)
+    r.len = (above ? __ffsll((long long)above) - 1 : n_valid) - lane;
+    return r;
+}
 __global__ void k_count_users(int64_t n, const int32_t* __restrict__ du, uint32_t* __restrict__ cnt) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) atomicAdd(&cnt[du[t]], 1u);
+    const bool valid = t < n;
+    const int32_t u = valid ? du[t] : -1;
+    const WaveRun r = wave_runs(u, valid);
+    if (r.head) atomicAdd(&cnt[u], (uint32_t)r.len);
 }
 static constexpr int SCAN_TILE = TPB * 8;
 // per tile of SCAN_TILE users: the number of their ratings; the longest row of all -> *max_len
@@ -361,13 +414,18 @@ __global__ void __launch_bounds__(TPB) k_user_ptr(int32_t U, uint32_t* __restric
 __global__ void k_scatter_rows(int64_t n, const int32_t* __restrict__ du, const int32_t* __restrict__ di,
                                const int64_t* __restrict__ u_ptr, uint32_t* __restrict__ cursor, unsigned long long* __restrict__ rows) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    const int32_t u = du[t];
-    const int64_t slot = u_ptr[u] + atomicAdd(&cursor[u], 1u);
+    const bool valid = t < n;
+    const int32_t u = valid ? du[t] : -1;
+    const WaveRun r = wave_runs(u, valid);
+    uint32_t base = 0;
+    if (r.head) base = atomicAdd(&cursor[u], (uint32_t)r.len);
+    base = __shfl(base, r.head_lane);
+    if (!valid) return;
+    const int64_t slot = u_ptr[u] + base + (uint32_t)((int)(threadIdx.x & 63) - r.head_lane);
     rows[slot] = ((unsigned long long)(uint32_t)di[t] << 32) | (uint32_t)t;
 }
 template <int CLASS>
-__global__ void __launch_bounds__(TPB) k_user_item_order(const int64_t* __restrict__ u_ptr, int32_t U, SegLists L,
+__global__ void __launch_bounds__(seg_threads(CLASS)) k_user_item_order(const int64_t* __restrict__ u_ptr, int32_t U, SegLists L,
                                                          const unsigned long long* __restrict__ rows, const double* __restrict__ rating,
                                                          int32_t* __restrict__ s_user, int32_t* __restrict__ s_col,
                                                          uint32_t* __restrict__ s_t, double* __restrict__ s_rating,
@@ -375,7 +433,7 @@ __global__ void __launch_bounds__(TPB) k_user_item_order(const int64_t* __restri
     extern __shared__ __attribute__((aligned(16))) char seg_smem[];
     constexpr bool BLOCK = CLASS >= 1;
     constexpr int CAP = CLASS == 0 ? SEG_SHORT_CAP : CLASS == 1 ? SEG_MID_CAP : SEG_BLOCK_CAP;
-    constexpr int THREADS = BLOCK ? TPB : 64;
+    constexpr int THREADS = BLOCK ? seg_threads(CLASS) : 64;
     constexpr int SEGS = BLOCK ? 1 : TPB / 64;
     const int wave = BLOCK ? 0 : (int)(threadIdx.x >> 6);
     const int tid = BLOCK ? (int)threadIdx.x : (int)(threadIdx.x & 63);
@@ -385,12 +443,8 @@ __global__ void __launch_bounds__(TPB) k_user_item_order(const int64_t* __restri
         const int32_t u = CLASS == 0 ? (int32_t)idx : (CLASS == 1 ? L.mid[idx] : L.longs[idx]);
         const int64_t b = u_ptr[u], e = u_ptr[u + 1];
         const int64_t n64 = e - b;
-        if (n64 > CAP) {  // (only class 0 meets these)
-            if (tid == 0) {
-                if (n64 <= SEG_MID_CAP) L.mid[atomicAdd(&L.counts[0], 1u)] = u;
-                else if (n64 <= SEG_BLOCK_CAP) L.longs[atomicAdd(&L.counts[1], 1u)] = u;
-                else atomicOr(status, (uint32_t)ST_LONG_ROW);
-            }
+        if (n64 > CAP) {  // (only class 0 meets these: they are on the lists)
+            if (n64 > SEG_BLOCK_CAP && tid == 0) atomicOr(status, (uint32_t)ST_LONG_ROW);
             continue;
         }
         const int32_t n = (int32_t)n64;
@@ -643,6 +697,7 @@ void prep_fit(Train& tr, PrepScratch& sc, int32_t shard_rank, int32_t shard_coun
     const int64_t n = tr.n;
     KN_REQUIRE(n > 0, KNNCF_E_INVALID, "fit: empty training set");
     KN_REQUIRE(n < (int64_t)1 << 29, KNNCF_E_UNSUPPORTED, "fit: more than 2^29-1 ratings (the kernels address the rating arrays with 32-bit byte offsets)");
+    if (sc.aux) KN_HIP(hipStreamSynchronize(sc.aux));  // (a fit that failed between fork and join may have left work there)
     sc.status.ensure(4);
     KN_HIP(hipMemsetAsync(sc.status.p, 0, 4 * sizeof(uint32_t), st));
     sc.k32_a.ensure(n); sc.k32_b.ensure(n); sc.v32_a.ensure(n); sc.v32_b.ensure(n);
@@ -793,26 +848,6 @@ void prep_fit(Train& tr, PrepScratch& sc, int32_t shard_rank, int32_t shard_coun
         k_invert<<<nblocks(n), TPB, 0, st>>>(n, tr.s_t.p, sc.perm_f.p);
         have_perm_f = true;
     };
-    if (seg_sorts) {
-        k_scatter_rows<<<nblocks(n), TPB, 0, st>>>(n, sc.du_row.p, sc.di_row.p, tr.u_ptr.p, sc.ucnt.p,
-                                                   reinterpret_cast<unsigned long long*>(sc.k64_a.p));
-        KN_HIP(hipMemsetAsync(sc.status.p + 2, 0, 2 * sizeof(uint32_t), st));  // (words 2, 3: the two list lengths)
-        static PerDeviceState lds2;
-        ensure_dynamic_lds(lds2, (const void*)k_user_item_order<2>, smem_key2);
-        const unsigned long long* rows = reinterpret_cast<const unsigned long long*>(sc.k64_a.p);
-        k_user_item_order<0><<<nblocks(U, TPB / 64), TPB, smem_key0, st>>>(tr.u_ptr.p, tr.U, L, rows, tr.rating.p, tr.s_user.p, tr.s_col.p, tr.s_t.p, tr.s_rating.p, sc.status.p);
-        k_user_item_order<1><<<2048, TPB, smem_key1, st>>>(tr.u_ptr.p, tr.U, L, rows, tr.rating.p, tr.s_user.p, tr.s_col.p, tr.s_t.p, tr.s_rating.p, sc.status.p);
-        k_user_item_order<2><<<256, TPB, smem_key2, st>>>(tr.u_ptr.p, tr.U, L, rows, tr.rating.p, tr.s_user.p, tr.s_col.p, tr.s_t.p, tr.s_rating.p, sc.status.p);
-    } else {
-        k_make_keys<<<nblocks(n), TPB, 0, st>>>(n, 0, sc.du_row.p, sc.di_row.p, tr.user_raw.p, tr.item_raw.p, sc.k64_a.p, ibits);
-        k_iota<<<nblocks(n), TPB, 0, st>>>(n, sc.v32_a.p);
-        KN_HIP(hipGetLastError());
-        sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.v32_a.p, tr.s_t.p, n, ibits + ubits, st);
-        k_unpack_positions<<<nblocks(n), TPB, 0, st>>>(n, sc.k64_b.p, tr.s_user.p, tr.s_col.p, sc.status.p, ibits);
-        k_gather_f64<<<nblocks(n), TPB, 0, st>>>(n, tr.s_t.p, tr.rating.p, tr.s_rating.p);
-    }
-    KN_HIP(hipGetLastError());
-
     // fold orders: the positions of every owned user re-ordered inside the user's segment
     // (the item-side fold orders belong to K4, which only the baseline predictors use: prep_item_stats)
     // usersAvg :113 sums a user's ratings in file order; dyadic ratings (every MovieLens file) sum exactly in ANY order, so a
@@ -822,26 +857,52 @@ void prep_fit(Train& tr, PrepScratch& sc, int32_t shard_rank, int32_t shard_coun
     else tr.perm_uf.release();
     if (n > 4) tr.perm_uh.alloc(n);  // a Map of <= 4 entries (Map1..Map4) iterates in insertion = file order (N4)
     else tr.perm_uh.release();
-    if (seg_sorts && hi > lo) {
-        // every owned user's segment sorted in LDS (three size classes), by file row and by (trie key of the tuple hash, file row)
-        static PerDeviceState lds1h, lds2h, lds1f, lds2f;
+    if (seg_sorts) {
+        // Every user's segment sorted in LDS: by item (the canonical order, all users), then — the owned users — by file row
+        // and by (trie key of the tuple hash, file row).  Three size classes; the two list classes run on the second stream.
+        static PerDeviceState lds2i, lds1h, lds2h, lds1f, lds2f;
+        ensure_dynamic_lds(lds2i, (const void*)k_user_item_order<2>, smem_key2);
         ensure_dynamic_lds(lds1h, (const void*)k_user_hash_order<1, false>, smem_pair1);
         ensure_dynamic_lds(lds2h, (const void*)k_user_hash_order<2, false>, smem_pair2);
         ensure_dynamic_lds(lds1f, (const void*)k_user_hash_order<1, true>, smem_pair1);
         ensure_dynamic_lds(lds2f, (const void*)k_user_hash_order<2, true>, smem_pair2);
-        if (need_uf) {
-            KN_HIP(hipMemsetAsync(sc.status.p + 2, 0, 2 * sizeof(uint32_t), st));
+        sc.ensure_aux();
+        hipStream_t sx = sc.aux;
+        k_scatter_rows<<<nblocks(n), TPB, 0, st>>>(n, sc.du_row.p, sc.di_row.p, tr.u_ptr.p, sc.ucnt.p,
+                                                   reinterpret_cast<unsigned long long*>(sc.k64_a.p));
+        KN_HIP(hipMemsetAsync(sc.status.p + 2, 0, 2 * sizeof(uint32_t), st));  // (words 2, 3: the two list lengths)
+        k_classify_rows<<<nblocks(U), TPB, 0, st>>>(tr.U, tr.u_ptr.p, L);
+        KN_HIP(hipGetLastError());
+        KN_HIP(hipEventRecord(sc.ev_fork, st));
+        KN_HIP(hipStreamWaitEvent(sx, sc.ev_fork, 0));
+        const unsigned long long* rows = reinterpret_cast<const unsigned long long*>(sc.k64_a.p);
+        const bool own = hi > lo;
+        k_user_item_order<2><<<256, seg_threads(2), smem_key2, sx>>>(tr.u_ptr.p, tr.U, L, rows, tr.rating.p, tr.s_user.p, tr.s_col.p, tr.s_t.p, tr.s_rating.p, sc.status.p);
+        k_user_item_order<1><<<2048, TPB, smem_key1, sx>>>(tr.u_ptr.p, tr.U, L, rows, tr.rating.p, tr.s_user.p, tr.s_col.p, tr.s_t.p, tr.s_rating.p, sc.status.p);
+        k_user_item_order<0><<<nblocks(U, TPB / 64), TPB, smem_key0, st>>>(tr.u_ptr.p, tr.U, L, rows, tr.rating.p, tr.s_user.p, tr.s_col.p, tr.s_t.p, tr.s_rating.p, sc.status.p);
+        if (need_uf && own) {
+            k_user_hash_order<2, true><<<256, seg_threads(2), smem_pair2, sx>>>(tr.u_ptr.p, lo, hi, L, tr.uid.p, tr.iid.p, tr.s_col.p, tr.s_t.p, tr.perm_uf.p, sc.status.p);
+            k_user_hash_order<1, true><<<2048, TPB, smem_pair1, sx>>>(tr.u_ptr.p, lo, hi, L, tr.uid.p, tr.iid.p, tr.s_col.p, tr.s_t.p, tr.perm_uf.p, sc.status.p);
             k_user_hash_order<0, true><<<nblocks(hi - lo, TPB / 64), TPB, smem_pair0, st>>>(tr.u_ptr.p, lo, hi, L, tr.uid.p, tr.iid.p, tr.s_col.p, tr.s_t.p, tr.perm_uf.p, sc.status.p);
-            k_user_hash_order<1, true><<<2048, TPB, smem_pair1, st>>>(tr.u_ptr.p, lo, hi, L, tr.uid.p, tr.iid.p, tr.s_col.p, tr.s_t.p, tr.perm_uf.p, sc.status.p);
-            k_user_hash_order<2, true><<<256, TPB, smem_pair2, st>>>(tr.u_ptr.p, lo, hi, L, tr.uid.p, tr.iid.p, tr.s_col.p, tr.s_t.p, tr.perm_uf.p, sc.status.p);
         }
-        if (n > 4) {
-            KN_HIP(hipMemsetAsync(sc.status.p + 2, 0, 2 * sizeof(uint32_t), st));
+        if (n > 4 && own) {
+            k_user_hash_order<2, false><<<256, seg_threads(2), smem_pair2, sx>>>(tr.u_ptr.p, lo, hi, L, tr.uid.p, tr.iid.p, tr.s_col.p, tr.s_t.p, tr.perm_uh.p, sc.status.p);
+            k_user_hash_order<1, false><<<2048, TPB, smem_pair1, sx>>>(tr.u_ptr.p, lo, hi, L, tr.uid.p, tr.iid.p, tr.s_col.p, tr.s_t.p, tr.perm_uh.p, sc.status.p);
             k_user_hash_order<0, false><<<nblocks(hi - lo, TPB / 64), TPB, smem_pair0, st>>>(tr.u_ptr.p, lo, hi, L, tr.uid.p, tr.iid.p, tr.s_col.p, tr.s_t.p, tr.perm_uh.p, sc.status.p);
-            k_user_hash_order<1, false><<<2048, TPB, smem_pair1, st>>>(tr.u_ptr.p, lo, hi, L, tr.uid.p, tr.iid.p, tr.s_col.p, tr.s_t.p, tr.perm_uh.p, sc.status.p);
-            k_user_hash_order<2, false><<<256, TPB, smem_pair2, st>>>(tr.u_ptr.p, lo, hi, L, tr.uid.p, tr.iid.p, tr.s_col.p, tr.s_t.p, tr.perm_uh.p, sc.status.p);
         }
-    } else if (!seg_sorts && shard_count == 1) {  // stable global sorts of the file-order sequence of positions
+        KN_HIP(hipGetLastError());
+        KN_HIP(hipEventRecord(sc.ev_join, sx));
+        KN_HIP(hipStreamWaitEvent(st, sc.ev_join, 0));
+    } else {
+        k_make_keys<<<nblocks(n), TPB, 0, st>>>(n, 0, sc.du_row.p, sc.di_row.p, tr.user_raw.p, tr.item_raw.p, sc.k64_a.p, ibits);
+        k_iota<<<nblocks(n), TPB, 0, st>>>(n, sc.v32_a.p);
+        KN_HIP(hipGetLastError());
+        sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.v32_a.p, tr.s_t.p, n, ibits + ubits, st);
+        k_unpack_positions<<<nblocks(n), TPB, 0, st>>>(n, sc.k64_b.p, tr.s_user.p, tr.s_col.p, sc.status.p, ibits);
+        k_gather_f64<<<nblocks(n), TPB, 0, st>>>(n, tr.s_t.p, tr.rating.p, tr.s_rating.p);
+    }
+    KN_HIP(hipGetLastError());
+    if (!seg_sorts && shard_count == 1) {  // stable global sorts of the file-order sequence of positions
         need_perm_f();
         if (need_uf) {
             k_copy_keys_u32<<<nblocks(n), TPB, 0, st>>>(n, sc.du_row.p, sc.k32_a.p);
