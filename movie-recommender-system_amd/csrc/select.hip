@@ -43,6 +43,9 @@ __device__ unsigned long long g_phase[16];
 // 10 % slower (and a 48 KiB-tile variant of an earlier version of this kernel 1.7x slower: tiles cost per tile).
 // __launch_bounds__(2 * TPB) caps the kernel at 128 VGPRs so that both workgroups fit.
 static constexpr int TPB = 512;
+#ifndef KNNCF_REFRESH_MASK
+#define KNNCF_REFRESH_MASK 0x4au  // tiles after which the threshold is refreshed from the stored values: 1, 3, 6 (A/B switch)
+#endif
 static constexpr int NBINS = 1024;
 static constexpr int TCOLS = SELECT_TCOLS;  // columns of the row held in LDS at a time (64 KiB)
 static constexpr int CPT = TCOLS / TPB;  // columns per thread per tile (32 = 4 groups of 8)
@@ -549,18 +552,21 @@ __global__ void __launch_bounds__(TPB, WAVES_PER_EU) k_tail_select(const ST* __r
         setup_b(0);
         __syncthreads();
     }
-    // histogram of every provisional value >= floor (values below the current threshold cannot be among the top k)
-    auto rebuild_hist = [&](float floor) {
-        for (int b2 = threadIdx.x; b2 < NBINS; b2 += TPB) hist[b2] = 0;
-        __syncthreads();
+    // The histogram of the provisional values is kept incrementally: a refresh adds the groups stored since the last one
+    // (values >= the threshold of that moment; the threshold only rises, so every value that can still be among the top k
+    // passes, and the bins below the threshold are never looked at) instead of zeroing it and re-reading the whole store —
+    // four rebuilds per row re-read ~3 x the store's final size, 70 KB per row at the ml-25m shape.
+    uint32_t counted = 0;  // groups already in the histogram (block-uniform)
+    auto count_new_groups = [&](float floor) {
         const uint32_t G = min(s_count, (uint32_t)GCAP);
-        for (uint32_t g = threadIdx.x; g < G; g += TPB) {
+        for (uint32_t g = counted + threadIdx.x; g < G; g += TPB) {
             const float4 a = g_x[2 * g], b4 = g_x[2 * g + 1];
             const float x8[8] = {a.x, a.y, a.z, a.w, b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
             for (int i = 0; i < 8; ++i)
                 if (x8[i] >= floor && x8[i] > -INFINITY) atomicAdd(&hist[sim_bin(x8[i])], 1u);
         }
+        counted = G;
         __syncthreads();
     };
     PH(0);  // preamble: collect, clears
@@ -729,8 +735,8 @@ __global__ void __launch_bounds__(TPB, WAVES_PER_EU) k_tail_select(const ST* __r
         // the store is filling up (wide error bands, e.g. bf16 operands)
         {
             const uint32_t prov = s_count;  // (block-uniform after the barrier)
-            if ((tile_no == 1 || tile_no == 3 || tile_no == 6 || prov > next_refresh) && prov <= (uint32_t)GCAP && t0 + TCOLS < U) {
-                rebuild_hist(s_thr);
+            if (((tile_no < 32 && ((KNNCF_REFRESH_MASK >> tile_no) & 1u)) || prov > next_refresh) && prov <= (uint32_t)GCAP && t0 + TCOLS < U) {
+                count_new_groups(s_thr);
                 block_threshold(hist, wtot, &s_thr, kk, eps);
                 next_refresh = max(next_refresh, prov + (uint32_t)GCAP / 8);  // (the store is not compacted: refresh again only after it has grown)
             }
@@ -742,7 +748,7 @@ __global__ void __launch_bounds__(TPB, WAVES_PER_EU) k_tail_select(const ST* __r
         if (threadIdx.x == 0) cand_cnt[r] = 0x7fffffff;
         return;
     }
-    rebuild_hist(s_thr);
+    count_new_groups(s_thr);
     block_threshold(hist, wtot, &s_thr, kk, eps);  // final: every value that can matter is in the histogram
     {
         const float thr = s_thr;
