@@ -168,7 +168,8 @@ void launch_row_len(const Train& tr, float* d_out, hipStream_t st) {
 
 // threshold from the cumulative histogram: lower edge of the bin holding the kk-th largest value seen so
 // far, minus 2 eps (-inf while fewer than kk values have been seen).  Thread t owns bins [4t, 4t+4).
-__device__ __forceinline__ void block_threshold(const uint32_t* hist, uint32_t* wtot, float* s_thr, int32_t kk, float eps) {
+// *s_bin = that bin (0 while fewer than kk values have been seen).
+__device__ __forceinline__ void block_threshold(const uint32_t* hist, uint32_t* wtot, float* s_thr, int32_t* s_bin, int32_t kk, float eps) {
     constexpr int PER = NBINS / TPB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t h[PER];
@@ -186,7 +187,7 @@ __device__ __forceinline__ void block_threshold(const uint32_t* hist, uint32_t* 
         if (lane + o < 64) suf += up;
     }
     if (lane == 0) wtot[wave] = suf;
-    if (threadIdx.x == 0) *s_thr = -INFINITY;
+    if (threadIdx.x == 0) { *s_thr = -INFINITY; *s_bin = 0; }
     __syncthreads();
     uint32_t higher = 0;  // values in the waves above mine
     for (int w = wave + 1; w < TPB / 64; ++w) higher += wtot[w];
@@ -203,6 +204,7 @@ __device__ __forceinline__ void block_threshold(const uint32_t* hist, uint32_t* 
         // every value in bin b is >= its lower edge (up to one float rounding of x + 1)
         const float edge = (float)b / (float)NBINS + HIST_LO;
         *s_thr = (b == 0) ? -INFINITY : edge - 2.0f * eps - 1e-6f;
+        *s_bin = b;
     }
     __syncthreads();
 }
@@ -269,6 +271,7 @@ __global__ void __launch_bounds__(TPB, WAVES_PER_EU) k_tail_select(const ST* __r
     float& s_thr = *reinterpret_cast<float*>(wtot + TPB / 64);
     uint32_t& s_count = wtot[TPB / 64 + 1];
     int32_t& s_ne = *reinterpret_cast<int32_t*>(wtot + TPB / 64 + 2);
+    int32_t& s_bin = *reinterpret_cast<int32_t*>(wtot2 + TPB / 64);  // bin of the threshold block_threshold found last (scratch cells)
     const int32_t r = blockIdx.x;
     if (r >= n_rows) return;
 #ifdef KNNCF_SELECT_PROFILE
@@ -552,6 +555,28 @@ __global__ void __launch_bounds__(TPB, WAVES_PER_EU) k_tail_select(const ST* __r
         setup_b(0);
         __syncthreads();
     }
+    // ANTICIPATED THRESHOLDS.  The k-th largest value seen so far is a valid threshold but a loose one early in the row:
+    // after one tile of ten it sits at the 1.8 % quantile of the row where the final one sits at 0.18 %, and half of all the
+    // groups a row stores come from its first two tiles.  Dense user indices are HashSet ranks of the raw ids, i.e. a tile is
+    // a pseudo-random sample of the users: of the row's k largest values a fraction f of the columns holds about k f, so
+    // after m tiles the emission threshold is taken at rank k f + 7 sqrt(k f (1 - f)) + 3 instead of k (never above k).
+    // That is a guess, and the kernel does not trust it: the final threshold is the exact k-th largest of what was stored,
+    // and every value of the row in a bin at or above the highest bin ever used for emission IS stored — so if the final
+    // threshold's bin is at or above that bin the store provably holds every value >= final threshold - 2 eps, as before;
+    // if it is below (the guess overshot: a 7-sigma event per refresh under the sampling model; any distribution is allowed) the row takes the
+    // exact fallback.  Rows of fewer than four tiles use the plain rank k throughout.
+    const int32_t n_tiles_row = (U + TCOLS - 1) / TCOLS;
+    auto rank_after = [&](int m) -> int32_t {  // rank of the emission threshold once m tiles are in the histogram
+#ifdef KNNCF_NO_ANTICIPATION
+        return kk;
+#endif
+        if (n_tiles_row < 4) return kk;
+        const float f = fminf(1.0f, (float)m * (float)TCOLS / (float)U);
+        const float mu = (float)kk * f;
+        const int32_t rk = (int32_t)ceilf(mu + 7.0f * sqrtf(mu * (1.0f - f)) + 3.0f);
+        return rk < kk ? max(rk, 1) : kk;
+    };
+    int32_t bin_used = 0;  // highest histogram bin an emission threshold was read from (block-uniform)
     // The histogram of the provisional values is kept incrementally: a refresh adds the groups stored since the last one
     // (values >= the threshold of that moment; the threshold only rises, so every value that can still be among the top k
     // passes, and the bins below the threshold are never looked at) instead of zeroing it and re-reading the whole store —
@@ -692,7 +717,8 @@ __global__ void __launch_bounds__(TPB, WAVES_PER_EU) k_tail_select(const ST* __r
                     if (sx[i] > -INFINITY) atomicAdd(&hist[sim_bin(sx[i])], 1u);
             }
             __syncthreads();
-            block_threshold(hist, wtot, &s_thr, kk, eps);
+            block_threshold(hist, wtot, &s_thr, &s_bin, rank_after(1), eps);
+            bin_used = max(bin_used, s_bin);
             for (int b = threadIdx.x; b < NBINS; b += TPB) hist[b] = 0;  // the real histogram starts below
             __syncthreads();
         }
@@ -737,7 +763,8 @@ __global__ void __launch_bounds__(TPB, WAVES_PER_EU) k_tail_select(const ST* __r
             const uint32_t prov = s_count;  // (block-uniform after the barrier)
             if (((tile_no < 32 && ((KNNCF_REFRESH_MASK >> tile_no) & 1u)) || prov > next_refresh) && prov <= (uint32_t)GCAP && t0 + TCOLS < U) {
                 count_new_groups(s_thr);
-                block_threshold(hist, wtot, &s_thr, kk, eps);
+                block_threshold(hist, wtot, &s_thr, &s_bin, rank_after(tile_no + 1), eps);
+                bin_used = max(bin_used, s_bin);
                 next_refresh = max(next_refresh, prov + (uint32_t)GCAP / 8);  // (the store is not compacted: refresh again only after it has grown)
             }
         }
@@ -749,7 +776,11 @@ __global__ void __launch_bounds__(TPB, WAVES_PER_EU) k_tail_select(const ST* __r
         return;
     }
     count_new_groups(s_thr);
-    block_threshold(hist, wtot, &s_thr, kk, eps);  // final: every value that can matter is in the histogram
+    block_threshold(hist, wtot, &s_thr, &s_bin, kk, eps);  // final: every value that can matter is in the histogram
+    if (s_bin < bin_used) {  // an anticipated threshold overshot (see rank_after): the store may lack a neighbour -> exact fallback
+        if (threadIdx.x == 0) cand_cnt[r] = 0x7fffffff;
+        return;
+    }
     {
         const float thr = s_thr;
         const uint32_t G = s_count;
