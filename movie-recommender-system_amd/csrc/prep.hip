@@ -877,16 +877,16 @@ void prep_fit(Train& tr, PrepScratch& sc, int32_t shard_rank, int32_t shard_coun
         KN_HIP(hipStreamWaitEvent(sx, sc.ev_fork, 0));
         const unsigned long long* rows = reinterpret_cast<const unsigned long long*>(sc.k64_a.p);
         const bool own = hi > lo;
-        k_user_item_order<2><<<256, seg_threads(2), smem_key2, sx>>>(tr.u_ptr.p, tr.U, L, rows, tr.rating.p, tr.s_user.p, tr.s_col.p, tr.s_t.p, tr.s_rating.p, sc.status.p);
+        k_user_item_order<2><<<1024, seg_threads(2), smem_key2, sx>>>(tr.u_ptr.p, tr.U, L, rows, tr.rating.p, tr.s_user.p, tr.s_col.p, tr.s_t.p, tr.s_rating.p, sc.status.p);
         k_user_item_order<1><<<2048, TPB, smem_key1, sx>>>(tr.u_ptr.p, tr.U, L, rows, tr.rating.p, tr.s_user.p, tr.s_col.p, tr.s_t.p, tr.s_rating.p, sc.status.p);
         k_user_item_order<0><<<nblocks(U, TPB / 64), TPB, smem_key0, st>>>(tr.u_ptr.p, tr.U, L, rows, tr.rating.p, tr.s_user.p, tr.s_col.p, tr.s_t.p, tr.s_rating.p, sc.status.p);
         if (need_uf && own) {
-            k_user_hash_order<2, true><<<256, seg_threads(2), smem_pair2, sx>>>(tr.u_ptr.p, lo, hi, L, tr.uid.p, tr.iid.p, tr.s_col.p, tr.s_t.p, tr.perm_uf.p, sc.status.p);
+            k_user_hash_order<2, true><<<1024, seg_threads(2), smem_pair2, sx>>>(tr.u_ptr.p, lo, hi, L, tr.uid.p, tr.iid.p, tr.s_col.p, tr.s_t.p, tr.perm_uf.p, sc.status.p);
             k_user_hash_order<1, true><<<2048, TPB, smem_pair1, sx>>>(tr.u_ptr.p, lo, hi, L, tr.uid.p, tr.iid.p, tr.s_col.p, tr.s_t.p, tr.perm_uf.p, sc.status.p);
             k_user_hash_order<0, true><<<nblocks(hi - lo, TPB / 64), TPB, smem_pair0, st>>>(tr.u_ptr.p, lo, hi, L, tr.uid.p, tr.iid.p, tr.s_col.p, tr.s_t.p, tr.perm_uf.p, sc.status.p);
         }
         if (n > 4 && own) {
-            k_user_hash_order<2, false><<<256, seg_threads(2), smem_pair2, sx>>>(tr.u_ptr.p, lo, hi, L, tr.uid.p, tr.iid.p, tr.s_col.p, tr.s_t.p, tr.perm_uh.p, sc.status.p);
+            k_user_hash_order<2, false><<<1024, seg_threads(2), smem_pair2, sx>>>(tr.u_ptr.p, lo, hi, L, tr.uid.p, tr.iid.p, tr.s_col.p, tr.s_t.p, tr.perm_uh.p, sc.status.p);
             k_user_hash_order<1, false><<<2048, TPB, smem_pair1, sx>>>(tr.u_ptr.p, lo, hi, L, tr.uid.p, tr.iid.p, tr.s_col.p, tr.s_t.p, tr.perm_uh.p, sc.status.p);
             k_user_hash_order<0, false><<<nblocks(hi - lo, TPB / 64), TPB, smem_pair0, st>>>(tr.u_ptr.p, lo, hi, L, tr.uid.p, tr.iid.p, tr.s_col.p, tr.s_t.p, tr.perm_uh.p, sc.status.p);
         }
