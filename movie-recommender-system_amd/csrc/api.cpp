@@ -448,6 +448,7 @@ void build_neighbors(knncf_handle* h, int32_t count) {
             // sparse tail (LDS atomics per row tile) + histogram select, fused: one pass over S
             Stage s(h, &h->tm.select_ms, sc);
             TailEntries te{h->te_cnt.p, h->te_item.p, h->te_x.p, h->row_tail_abs.p, h->row_head_sq.p, h->row_len.p};
+            h->prep.join_commit(sc);  // the item-major rater lists and the tile table (second part of prep_commit)
             launch_tail_select(tr, h->colmap.p, te, head < tr.I, use_sym ? h->S_full.p : h->S[slot].p, use_sym, s_fp16, U_pad, rows, d_rows, nt.k, eps_opnd, eps_rest, cap,
                                h->sel.cand_idx.p, h->sel.cand_approx.p, h->sel.cand_cnt.p, h->sel.cand_eps.p, h->sel.grp_v0.p, h->sel.grp_x.p, select_gcap(nt.k), sc);
             h->tm.select_launches += 1;
@@ -563,6 +564,7 @@ void ensure_personalized_table(knncf_handle* h) {
 void ensure_item_stats(knncf_handle* h) {
     if (h->tr.item_stats_ready) return;
     Stage s(h, &h->tm.prep_ms);
+    h->prep.join_commit(h->stream);
     prep_item_stats(h->tr, h->prep, h->stream);
 }
 
@@ -595,6 +597,7 @@ void run_predict(knncf_handle* h, int predictor, const int32_t* d_users, const i
         launch_dense_ids(tr, d_users, d_items, n, h->t_du.p, h->t_di.p, st);
     }
     if (kind == KNNCF_PRED_KNN && table == &h->nt) ensure_neighbors_for_rows(h, n);
+    h->prep.join_commit(st);  // the item-major copies and the rater bitmaps (second part of prep_commit)
     {
         Stage s(h, &h->tm.predict_ms);
         double* pred = d_pred_out ? d_pred_out : h->t_pred.p;

@@ -105,7 +105,12 @@ struct PrepScratch {
     DArr<uint4> rec;        // [2 n] (preprocessed rating, deviation | user, file row) records: one 32-byte gather per entry
     // second stream of the fit: the per-user LDS sorts of the few long rows run beside those of everybody else
     hipStream_t aux = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_commit = nullptr;
+    // prep_commit leaves its second part (item-major copies, tile table, rater bitmaps) running on `aux`: whoever reads
+    // those (select.hip, predict.hip) or re-uses this scratch for more than a sort (prep_item_stats) joins first
+    bool commit_pending = false;
+    DArr<uint32_t> perm_iu;  // [n] positions in (item, user ascending) order
+    void join_commit(hipStream_t st);
     void ensure_aux();
     void release_all();
     PrepScratch() = default;

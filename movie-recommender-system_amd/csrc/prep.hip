@@ -24,17 +24,24 @@ void PrepScratch::ensure_aux() {
     KN_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
     KN_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     KN_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    KN_HIP(hipEventCreateWithFlags(&ev_commit, hipEventDisableTiming));
+}
+void PrepScratch::join_commit(hipStream_t st) {
+    if (!commit_pending) return;
+    KN_HIP(hipStreamWaitEvent(st, ev_commit, 0));
+    commit_pending = false;
 }
 PrepScratch::~PrepScratch() {
     if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); }
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
+    if (ev_commit) (void)hipEventDestroy(ev_commit);
 }
 
 void PrepScratch::release_all() {
     sort.tmp.release();
     k64_a.release(); k64_b.release(); v32_a.release(); v32_b.release();
-    k32_a.release(); k32_b.release(); du_row.release(); di_row.release(); perm_f.release(); rec.release(); long_rows.release(); ucnt.release(); utile.release();
+    k32_a.release(); k32_b.release(); du_row.release(); di_row.release(); perm_f.release(); rec.release(); long_rows.release(); ucnt.release(); utile.release(); perm_iu.release();
 }
 
 // ---- K0: ids ---------------------------------------------------------------------------
@@ -698,6 +705,7 @@ void prep_fit(Train& tr, PrepScratch& sc, int32_t shard_rank, int32_t shard_coun
     KN_REQUIRE(n > 0, KNNCF_E_INVALID, "fit: empty training set");
     KN_REQUIRE(n < (int64_t)1 << 29, KNNCF_E_UNSUPPORTED, "fit: more than 2^29-1 ratings (the kernels address the rating arrays with 32-bit byte offsets)");
     if (sc.aux) KN_HIP(hipStreamSynchronize(sc.aux));  // (a fit that failed between fork and join may have left work there)
+    sc.commit_pending = false;
     sc.status.ensure(4);
     KN_HIP(hipMemsetAsync(sc.status.p, 0, 4 * sizeof(uint32_t), st));
     sc.k32_a.ensure(n); sc.k32_b.ensure(n); sc.v32_a.ensure(n); sc.v32_b.ensure(n);
@@ -1105,6 +1113,12 @@ __global__ void k_pop_keys(int32_t I, int32_t U, const int64_t* __restrict__ i_p
     val[i] = (uint32_t)i;
 }
 
+// Two parts.  Part A, on the caller's stream: the (item, user ascending) order of the positions, i_ptr and the popularity
+// order — what the hybrid similarity's head choice and the operand panel need.  Part B — the 32-byte records, the item-major
+// copies, the tile table and the rater bitmaps, 1.2 ms of mostly HBM writes (1.8 GB of bitmaps) — is only read by select.hip
+// and predict.hip, so it runs on the fit's second stream beside whatever the caller queues next (the operand panel and the
+// similarity GEMM); its consumers call sc.join_commit(stream) first (api.cpp).  Part B reads no shared scratch buffer the
+// caller's stream may overwrite meanwhile (perm_iu and rec are its own).
 void prep_commit(Train& tr, PrepScratch& sc, hipStream_t st) {
     const int64_t n = tr.n;
     const int32_t I = tr.I;
@@ -1112,21 +1126,14 @@ void prep_commit(Train& tr, PrepScratch& sc, hipStream_t st) {
     // (item, user ascending) order: a stable sort of the user-major positions by item
     tr.it_user.alloc(n); tr.it_pack.alloc(n); tr.it_dev.alloc(n); tr.it_t.alloc(n); tr.pop_item.alloc(I);
     sc.k64_a.ensure(std::max<int64_t>(n, I)); sc.k64_b.ensure(std::max<int64_t>(n, I));
-    sc.v32_a.ensure(std::max<int64_t>(n, I)); sc.v32_b.ensure(n);
+    sc.v32_a.ensure(std::max<int64_t>(n, I)); sc.perm_iu.ensure(n);
     sc.k32_a.ensure(n); sc.k32_b.ensure(n);
-    k_col_keys<<<nblocks(n), TPB, 0, st>>>(n, tr.s_col.p, sc.k32_a.p, sc.v32_a.p);
-    KN_HIP(hipGetLastError());
-    sort_pairs_u32_u32(sc.sort, sc.k32_a.p, sc.k32_b.p, sc.v32_a.p, sc.v32_b.p, n, bits_for(I), st);
-    k_segment_ptr_u32<<<nblocks((int64_t)I + 1), TPB, 0, st>>>(n, sc.k32_b.p, I, tr.i_ptr.p);
     sc.rec.ensure(2 * (size_t)n);
-    k_pack_records<<<nblocks(n), TPB, 0, st>>>(n, tr.s_user.p, tr.s_pre.p, tr.s_dev.p, tr.s_t.p, sc.rec.p);
-    k_item_major<<<nblocks(n), TPB, 0, st>>>(n, sc.v32_b.p, sc.rec.p, tr.it_user.p, tr.it_pack.p, tr.it_dev.p, tr.it_t.p, tr.jaccard ? 1 : 0);
     tr.tile_stride = (int32_t)ceil_div(tr.U, SELECT_TCOLS) + 1;
     tr.it_tile.ensure((size_t)I * tr.tile_stride);
-    k_item_tiles<<<nblocks((int64_t)I * tr.tile_stride), TPB, 0, st>>>(I, tr.tile_stride, tr.i_ptr.p, tr.it_user.p, tr.it_tile.p);
     // per-item rater bitmaps + rank prefixes for the prediction probes (skipped when they would not fit)
+    const int64_t words = ceil_div(tr.U, 64);
     {
-        const int64_t words = ceil_div(tr.U, 64);
         const double bytes = (double)I * (double)words * 12.0;
         size_t free_b = 0, total_b = 0;
         KN_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -1135,14 +1142,34 @@ void prep_commit(Train& tr, PrepScratch& sc, hipStream_t st) {
             tr.ib_words = words;
             tr.item_bits.ensure((size_t)I * words);
             tr.item_rank.ensure((size_t)I * words);
-            k_item_bits_rank<<<nblocks((int64_t)I * (tr.tile_stride - 1) * 64), TPB, 0, st>>>(
-                I, words, tr.i_ptr.p, tr.it_user.p, tr.it_tile.p, tr.tile_stride, reinterpret_cast<unsigned long long*>(tr.item_bits.p),
-                tr.item_rank.p);
-            KN_HIP(hipGetLastError());
         } else {
             tr.ib_words = 0;
         }
     }
+    sc.ensure_aux();
+    // ---- part A
+    k_col_keys<<<nblocks(n), TPB, 0, st>>>(n, tr.s_col.p, sc.k32_a.p, sc.v32_a.p);
+    KN_HIP(hipGetLastError());
+    sort_pairs_u32_u32(sc.sort, sc.k32_a.p, sc.k32_b.p, sc.v32_a.p, sc.perm_iu.p, n, bits_for(I), st);
+    k_segment_ptr_u32<<<nblocks((int64_t)I + 1), TPB, 0, st>>>(n, sc.k32_b.p, I, tr.i_ptr.p);
+    KN_HIP(hipGetLastError());
+    // ---- part B, forked
+    {
+        hipStream_t sx = sc.aux;
+        KN_HIP(hipEventRecord(sc.ev_fork, st));
+        KN_HIP(hipStreamWaitEvent(sx, sc.ev_fork, 0));
+        k_pack_records<<<nblocks(n), TPB, 0, sx>>>(n, tr.s_user.p, tr.s_pre.p, tr.s_dev.p, tr.s_t.p, sc.rec.p);
+        k_item_major<<<nblocks(n), TPB, 0, sx>>>(n, sc.perm_iu.p, sc.rec.p, tr.it_user.p, tr.it_pack.p, tr.it_dev.p, tr.it_t.p, tr.jaccard ? 1 : 0);
+        k_item_tiles<<<nblocks((int64_t)I * tr.tile_stride), TPB, 0, sx>>>(I, tr.tile_stride, tr.i_ptr.p, tr.it_user.p, tr.it_tile.p);
+        if (tr.ib_words > 0)
+            k_item_bits_rank<<<nblocks((int64_t)I * (tr.tile_stride - 1) * 64), TPB, 0, sx>>>(
+                I, words, tr.i_ptr.p, tr.it_user.p, tr.it_tile.p, tr.tile_stride, reinterpret_cast<unsigned long long*>(tr.item_bits.p),
+                tr.item_rank.p);
+        KN_HIP(hipGetLastError());
+        KN_HIP(hipEventRecord(sc.ev_commit, sx));
+        sc.commit_pending = true;
+    }
+    // ---- part A, continued
     k_pop_keys<<<nblocks(I), TPB, 0, st>>>(I, tr.U, tr.i_ptr.p, sc.k64_a.p, sc.v32_a.p);
     KN_HIP(hipGetLastError());
     sort_pairs_u64_u32(sc.sort, sc.k64_a.p, sc.k64_b.p, sc.v32_a.p, reinterpret_cast<uint32_t*>(tr.pop_item.p), I, bits_for((uint64_t)tr.U), st);

@@ -44,7 +44,8 @@ __device__ unsigned long long g_phase[16];
 // __launch_bounds__(2 * TPB) caps the kernel at 128 VGPRs so that both workgroups fit.
 static constexpr int TPB = 512;
 #ifndef KNNCF_REFRESH_MASK
-#define KNNCF_REFRESH_MASK 0x4au  // tiles after which the threshold is refreshed from the stored values: 1, 3, 6 (A/B switch)
+#define KNNCF_REFRESH_MASK 0x8u  // tiles after which the threshold is refreshed from the stored values: 3 (A/B switch; 1, 3, 6
+                                 // before the thresholds were anticipated)
 #endif
 static constexpr int NBINS = 1024;
 static constexpr int TCOLS = SELECT_TCOLS;  // columns of the row held in LDS at a time (64 KiB)
