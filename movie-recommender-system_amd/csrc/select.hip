@@ -12,8 +12,9 @@
 //   2. the tile's final values S + tail stay in registers; every GROUP of 8 columns whose maximum reaches the
 //      threshold known so far is stored whole in a per-row provisional store in global memory (gcap groups, scaled with
 //      k).  The threshold — lower edge of the bin that holds the k-th largest value of a 1024-bin histogram, minus 2 eps —
-//      is bootstrapped from the first tile and refreshed from the stored values (after tiles 1, 3, 6 and whenever the
-//      store has grown); it can only rise, so a stale one merely lets more through;
+//      is bootstrapped from the first tile at an ANTICIPATED rank (see rank_after below: a guess that the final, exact
+//      threshold verifies) and refreshed from the stored values (after 16 and 32 tiles and whenever the store has grown);
+//      a loose one merely lets more through;
 //   3. after the last tile the threshold is final and the stored values are sorted out once into the shortlist.
 // With |S[u][v] - s_uv| <= eps for every pair, every true top-k member v satisfies
 // S[u][v] >= a_k - 2 eps (a_k = k-th largest value of the row), so the shortlist provably contains
@@ -44,8 +45,10 @@ __device__ unsigned long long g_phase[16];
 // __launch_bounds__(2 * TPB) caps the kernel at 128 VGPRs so that both workgroups fit.
 static constexpr int TPB = 512;
 #ifndef KNNCF_REFRESH_MASK
-#define KNNCF_REFRESH_MASK 0x8u  // tiles after which the threshold is refreshed from the stored values: 3 (A/B switch; 1, 3, 6
-                                 // before the thresholds were anticipated)
+#define KNNCF_REFRESH_MASK 0x80008000u  // tiles after which the threshold is refreshed from the stored values (A/B switch): after
+                                        // 16 and 32 tiles — none at the ml-25m shape's ten tiles: with the anticipated thresholds
+                                        // a refresh there costs more than the groups it saves; the store's fill
+                                        // level still triggers one whenever it grows
 #endif
 static constexpr int NBINS = 1024;
 static constexpr int TCOLS = SELECT_TCOLS;  // columns of the row held in LDS at a time (64 KiB)
@@ -702,13 +705,14 @@ __global__ void __launch_bounds__(TPB, WAVES_PER_EU) k_tail_select(const ST* __r
             // of any set of maxima over disjoint column sets is a lower bound of the kk-th largest value of the row,
             // and a tight one (the top values sit in different threads) — with one histogram atomic per maximum
             // instead of one per column.
-            if (NG >= 4 && kk <= (TCOLS / 32) / 3) {  // maxima over 4 groups = 32 columns
+            const int32_t kk0 = rank_after(1);  // (the rank this histogram will be asked for)
+            if (NG >= 4 && kk0 <= (TCOLS / 32) / 3) {  // maxima over 4 groups = 32 columns
 #pragma unroll
                 for (int j = 0; j + 3 < NG; j += 4) {
                     const float m = fmaxf(fmaxf(gm[j], gm[j + 1]), fmaxf(gm[j + 2], gm[j + 3]));
                     if (m > -INFINITY) atomicAdd(&hist[sim_bin(m)], 1u);
                 }
-            } else if (kk <= (TCOLS / 8) / 3) {
+            } else if (kk0 <= (TCOLS / 8) / 3) {
 #pragma unroll
                 for (int j = 0; j < NG; ++j)
                     if (gm[j] > -INFINITY) atomicAdd(&hist[sim_bin(gm[j])], 1u);
@@ -718,7 +722,7 @@ __global__ void __launch_bounds__(TPB, WAVES_PER_EU) k_tail_select(const ST* __r
                     if (sx[i] > -INFINITY) atomicAdd(&hist[sim_bin(sx[i])], 1u);
             }
             __syncthreads();
-            block_threshold(hist, wtot, &s_thr, &s_bin, rank_after(1), eps);
+            block_threshold(hist, wtot, &s_thr, &s_bin, kk0, eps);
             bin_used = max(bin_used, s_bin);
             for (int b = threadIdx.x; b < NBINS; b += TPB) hist[b] = 0;  // the real histogram starts below
             __syncthreads();
