@@ -282,8 +282,9 @@ def main():
         }
         ts["binding"] = ("latency / synchronisation, not a throughput roof: SQ pass of profiles/" + PMC_PROFILE + " — VALU issue ~54 % "
                          "(0.135 instructions per wave-quad-cycle x 4 waves per SIMD), waves waiting 52 %; timing-only ablations "
-                         "(DESIGN.md section 4): panel scan + thresholds 16.5 ms of the 35.6 ms kernel at H = 256, tail set-up / read-out "
-                         "4.4, tail drain 14.6 (6.2 of it loads + LDS atomics, 8.4 instruction issue at 8 VALU per 64-entry piece). "
+                         "of an earlier build of this kernel (DESIGN.md section 4; 35.6 ms at H = 256, 26.7 ms now): panel scan + thresholds 16.5 ms, "
+                         "tail set-up / read-out 4.4, tail drain 14.6 (6.2 of it loads + LDS atomics, 8.4 instruction issue at 8 VALU per "
+                         "64-entry piece); the provisional store's re-reads and its loose early thresholds have since been removed. "
                          "HBM frac on compulsory bytes and the LDS-atomic frac are both reported")
         stage_of = {"k_gemm_nt_bf16": "gemm_ms", "k_tail_select": "select_ms", "k_rerank": "rerank_ms", "k_predict_knn": "predict_ms"}
         dominant = max(stage_of, key=lambda n: tm[stage_of[n]])

@@ -375,13 +375,18 @@ void build_neighbors(knncf_handle* h, int32_t count) {
     size_t held = 0;
     for (int s = 0; s < 2; ++s) held += h->S[s].bytes() + h->Apanel[s].bytes();
     held += h->sel.cand_idx.bytes() + h->sel.cand_approx.bytes() + h->sel.grp_v0.bytes() + h->sel.grp_x.bytes();
-    // (a third of what is free, at most 96 GB: at the ml-25m shape every row then fits ONE block — 69 GB of shortlist and
-    // group stores beside the 53 GB panel — and select and re-rank run as one launch each: a launch's tail of unfinished
-    // rows is paid once, 0.5 ms per step against two blocks)
     int64_t budget = h->cfg.workspace_bytes > 0 ? h->cfg.workspace_bytes / 2
-                                                : (int64_t)std::min<size_t>((size_t)96 << 30, (free_b + held) / 3);
+                                                : (int64_t)std::min<size_t>((size_t)48 << 30, (free_b + held) / 4);
     // per panel row: the similarity row, the operand row, the shortlist store and the provisional group store
     int64_t per_row = (use_sym ? 0 : U_pad * s_elem + K_pad * 2) + (int64_t)shortlist_cap(nt.k, tr.U) * 8 + (int64_t)select_gcap(nt.k) * 36;
+    // When ALL rows fit a third of what is free (at most 96 GB) they are ONE block: at the ml-25m shape 69 GB of shortlist and
+    // group stores beside the 53 GB panel, select and re-rank then run as one launch each and a launch's tail of unfinished
+    // rows is paid once (0.5 ms per step against two blocks).  Shapes that need several blocks anyway keep the 48 GB
+    // budget: allocating more only costs (syn-1M, one shot: 1.7 s of extra hipMalloc time for 96 GB blocks).
+    if (h->cfg.workspace_bytes <= 0) {
+        const int64_t whole = round_up(count, 256) * per_row;
+        if (whole <= (int64_t)std::min<size_t>((size_t)96 << 30, (free_b + held) / 3)) budget = std::max(budget, whole);
+    }
     int64_t R = std::max<int64_t>(256, (budget / per_row) / 256 * 256);
     R = std::min<int64_t>(R, round_up(count, 256));
     const int64_t n_blocks = ceil_div(count, R);
