@@ -22,7 +22,7 @@ static constexpr int SELECT_TCOLS = KNNCF_TCOLS;  // <= 2^15: it_pack keeps the 
 // ---- sort_util.hip (stable LSD radix sort / sorted-unique, hand-written; K0 plumbing) ----
 struct SortWorkspace {
     DArr<char> tmp;
-    DArr<size_t> count;  // result cell of unique_u32 (kept: a hipFree per call synchronises the device)
+    DArr<size_t> count;  // unique_u32's per-tile counts and result cell (raw storage; kept: a hipFree per call synchronises the device)
 };
 void sort_pairs_u64_u32(SortWorkspace& ws, const uint64_t* kin, uint64_t* kout, const uint32_t* vin,
                         uint32_t* vout, size_t n, int end_bit, hipStream_t st);
