@@ -483,10 +483,16 @@ __global__ void __launch_bounds__(TPB, WAVES_PER_EU) k_tail_select(const ST* __r
 #define KN_TAIL_ADD "ds_add_u32 %[a], %[t]\n\t"
 #endif
 // piece (group base %[sg]) + OFF: start of the piece -> byte offset in a scalar, the load of its 64 entries into W
+#ifdef KNNCF_ABL_HOTLOAD  /* timing-only ablation (results are wrong): every piece is read out of the array's first 16 KiB, i.e. the L1/L2 */
+#define KN_TAIL_HOT "s_and_b32 %[sq], %[sq], 0x3ffc\n\t"
+#else
+#define KN_TAIL_HOT
+#endif
 #define KN_TAIL_ISSUE(W, OFF)                                              \
     "s_add_u32 %[sj], %[sg], " #OFF "\n\t"                                 \
     "v_readlane_b32 %[sq], %[dq], %[sj]\n\t"                               \
     "s_lshl_b32 %[sq], %[sq], 2\n\t"                                       \
+    KN_TAIL_HOT                                                            \
     KN_TAIL_LOAD(W)
 // piece (group base %[sg]) + OFF: wait until at most N younger loads are in flight, products, cell addresses, the atomics
 // under the piece's lane mask
