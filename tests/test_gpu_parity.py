@@ -580,6 +580,29 @@ def test_full_size_ml25m_shape_every_row_against_the_oracle(kn, oracle, full25m)
     assert sb / cb == pytest.approx(want_b, abs=MAE_TOL)
 
 
+@pytest.mark.parametrize("k", [30, 1000])
+def test_full_size_ml25m_shape_other_k_bulk_lists(kn, oracle, full25m, k):
+    """The headline shape at a small and a large k: select.hip anticipates its emission thresholds from the rank k f +
+    7 sqrt(k f (1 - f)) + 3 (f = fraction of the row seen), which behaves differently at k = 30 (the anticipated rank is
+    close to k) and k = 1000 (far below it, 1024-entry shortlist tiles in the re-rank).  Every user's neighbour list (ids and
+    fp64 similarities) against the oracle's bulk form, the error band verified, no fallback row."""
+    f = full25m
+    m = f["model"]
+    e = kn.Engine(k=k, flags=kn.FLAG_VERIFY_BOUND)
+    try:
+        e.fit_device(*f["tr"])
+        table = m.knn_table(k)
+        ids, sims, counts = e.neighbors_batch(table.row_user)
+        t = e.timings()
+        assert t["fallback_rows"] == 0 and t["max_bound_violation"] <= 0.0
+        assert (counts == k).all()
+        bad = np.flatnonzero((ids != table.ids).any(axis=1))
+        assert len(bad) == 0, f"{len(bad)} neighbour lists differ at k = {k}, first user {table.row_user[bad[0]]}"
+        assert np.array_equal(sims.view(np.int64), table.sims.view(np.int64))
+    finally:
+        e.close()
+
+
 def test_ml25m_shape_eight_shards_on_one_gpu(kn, pkg, full25m):
     """BASELINE config 4 (kNN k = 300 on ml-25m shape, users sharded x8) rehearsed on ONE GPU: eight handles with
     shard_rank 0..7 go through the C-ABI shard protocol (fit -> view -> exchange -> commit -> partial MAE); the exchange
