@@ -354,7 +354,9 @@ void build_neighbors(knncf_handle* h, int32_t count) {
         const int32_t n_tiles = (int32_t)(U_pad / sym_tile);
         if (h->sym_tiles_n != n_tiles) {
             std::vector<uint32_t> list;
-            gemm_sym_tile_list(n_tiles, list, sym_tile == 128 ? 16 : 8);
+            int group = sym_tile == 128 ? 16 : 8;
+            if (const char* g = getenv("KNNCF_GEMM_SYM_GROUP")) group = std::max(1, atoi(g));  // A/B switch for measurements
+            gemm_sym_tile_list(n_tiles, list, group);
             h->sym_tiles.ensure(list.size());
             KN_HIP(hipMemcpyAsync(h->sym_tiles.p, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
             KN_HIP(hipStreamSynchronize(st));
