@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(TPB, WAVES_PER_EU) k_tail_select(const ST* __r
                                                      int32_t kk, float eps_opnd, float eps_rest, int32_t cap, int32_t* __restrict__ cand_idx,
                                                      float* __restrict__ cand_approx, int32_t* __restrict__ cand_cnt,
                                                      float* __restrict__ cand_eps, int32_t* __restrict__ grp_v0,
-                                                     float* __restrict__ grp_x, int32_t GCAP) {
+                                                     float* __restrict__ grp_x, int32_t GCAP, float ant_sigma) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int32_t* itile = reinterpret_cast<int32_t*>(smem);            // [TCOLS] tail accumulator, Q7.24, cell layout of it_pack
     uint32_t* hist = reinterpret_cast<uint32_t*>(itile + TCOLS);  // [NBINS]
@@ -569,7 +569,8 @@ __global__ void __launch_bounds__(TPB, WAVES_PER_EU) k_tail_select(const ST* __r
     // after one tile of ten it sits at the 1.8 % quantile of the row where the final one sits at 0.18 %, and half of all the
     // groups a row stores come from its first two tiles.  Dense user indices are HashSet ranks of the raw ids, i.e. a tile is
     // a pseudo-random sample of the users: of the row's k largest values a fraction f of the columns holds about k f, so
-    // after m tiles the emission threshold is taken at rank k f + 7 sqrt(k f (1 - f)) + 3 instead of k (never above k).
+    // after m tiles the emission threshold is taken at rank k f + sigma sqrt(k f (1 - f)) + 3 instead of k (never above k;
+    // sigma = 7, launch_tail_select).
     // That is a guess, and the kernel does not trust it: the final threshold is the exact k-th largest of what was stored,
     // and every value of the row in a bin at or above the highest bin ever used for emission IS stored — so if the final
     // threshold's bin is at or above that bin the store provably holds every value >= final threshold - 2 eps, as before;
@@ -577,13 +578,10 @@ __global__ void __launch_bounds__(TPB, WAVES_PER_EU) k_tail_select(const ST* __r
     // exact fallback.  Rows of fewer than four tiles use the plain rank k throughout.
     const int32_t n_tiles_row = (U + TCOLS - 1) / TCOLS;
     auto rank_after = [&](int m) -> int32_t {  // rank of the emission threshold once m tiles are in the histogram
-#ifdef KNNCF_NO_ANTICIPATION
-        return kk;
-#endif
-        if (n_tiles_row < 4) return kk;
+        if (ant_sigma < 0.0f || n_tiles_row < 4) return kk;
         const float f = fminf(1.0f, (float)m * (float)TCOLS / (float)U);
         const float mu = (float)kk * f;
-        const int32_t rk = (int32_t)ceilf(mu + 7.0f * sqrtf(mu * (1.0f - f)) + 3.0f);
+        const int32_t rk = (int32_t)ceilf(mu + ant_sigma * sqrtf(mu * (1.0f - f)) + 3.0f);
         return rk < kk ? max(rk, 1) : kk;
     };
     int32_t bin_used = 0;  // highest histogram bin an emission threshold was read from (block-uniform)
@@ -857,7 +855,15 @@ static void launch_tail_select_t(const TailArgs& T, const ST* S, bool s_by_user,
     const size_t smem = (size_t)TCOLS * 4 + (size_t)NBINS * 4 + (size_t)EMAX * 4 + 2 * ((size_t)EMAX * 12 + (size_t)PMAX * 2) + (2 * (TPB / 64) + 4 + 64) * 4;  // + 64 scratch cells
     static PerDeviceState lds_state;
     ensure_dynamic_lds(lds_state, (const void*)k_tail_select<ST, JAC>, smem);
-    k_tail_select<ST, JAC><<<n_rows, TPB, smem, st>>>(S, s_by_user ? 1 : 0, lds, n_rows, d_row_user, T, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap);
+    // (KNNCF_DEBUG_ANTICIPATE_SIGMA: test hook — a small margin makes the anticipated thresholds overshoot in some rows, which
+    // must then be caught by the final check and rebuilt exactly; a negative one switches the anticipation off)
+#ifdef KNNCF_NO_ANTICIPATION
+    const float ant_sigma = -1.0f;
+#else
+    const char* sg = getenv("KNNCF_DEBUG_ANTICIPATE_SIGMA");
+    const float ant_sigma = sg ? (float)atof(sg) : 7.0f;
+#endif
+    k_tail_select<ST, JAC><<<n_rows, TPB, smem, st>>>(S, s_by_user ? 1 : 0, lds, n_rows, d_row_user, T, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, ant_sigma);
     KN_HIP(hipGetLastError());
 #ifdef KNNCF_SELECT_PROFILE
     KN_HIP(hipStreamSynchronize(st));

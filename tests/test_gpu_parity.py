@@ -436,6 +436,37 @@ def test_wide_shape_takes_the_large_u_paths(kn, oracle, synth):
     e.close()
 
 
+def test_overshooting_anticipated_thresholds_are_caught(kn, synth, monkeypatch):
+    """select.hip emits against ANTICIPATED thresholds (rank k f + 7 sigma ... of the columns seen) and verifies them at the
+    end of the row; with the margin cut to 1.5 sigma (test hook) the guess overshoots in some rows, the final check must
+    notice, and those rows are rebuilt exactly: every neighbour list then still equals the default build's, which the
+    full-size and wide-shape tests pin to the oracle."""
+    import torch
+
+    d = synth.syn_scaled(90_000, 3_000, 3_000_000, seed=31, half_stars=True)   # six column tiles
+    dev = torch.device("cuda", 0)
+    tr = tuple(torch.from_numpy(a).to(dev) for a in (d.train.users, d.train.items, d.train.ratings))
+    users = np.unique(d.train.users)
+    out = {}
+    for sigma in (None, "1.5", "-1"):
+        if sigma is None:
+            monkeypatch.delenv("KNNCF_DEBUG_ANTICIPATE_SIGMA", raising=False)
+        else:
+            monkeypatch.setenv("KNNCF_DEBUG_ANTICIPATE_SIGMA", sigma)
+        e = kn.Engine(k=100, flags=kn.FLAG_VERIFY_BOUND)
+        e.fit_device(*tr)
+        ids, sims, counts = e.neighbors_batch(users)
+        t = e.timings()
+        assert t["max_bound_violation"] <= 0.0
+        out[sigma] = (ids, sims, counts, t["fallback_rows"])
+        e.close()
+    assert out[None][3] == 0 and out["-1"][3] == 0        # 7 sigma / no anticipation: no row needs the fallback
+    assert 0 < out["1.5"][3] < len(users) // 10           # the hook really produced overshoots, and not everywhere
+    for sigma in ("1.5", "-1"):
+        assert np.array_equal(out[sigma][0], out[None][0]) and np.array_equal(out[sigma][2], out[None][2])
+        assert np.array_equal(out[sigma][1].view(np.int64), out[None][1].view(np.int64))
+
+
 def test_ids_outside_the_direct_tables(kn, oracle, synth, monkeypatch):
     """raw ids that are negative or >= 2^24 (not MovieLens, but legal Ints for `load`) take the general id path: every row's
     key sorted + unique, hash + binary search per row; and the same path forced on ordinary ids"""
