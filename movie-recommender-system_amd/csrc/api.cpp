@@ -59,6 +59,7 @@ struct knncf_handle {
     DArr<float> S[2];
     DArr<float> S_full;            // symmetric path: the whole U_pad x U_pad similarity panel (raw storage)
     DArr<uint32_t> sym_tiles;      // its tile order (gemm_sym_tile_list), cached per U_pad
+    DArr<int32_t> redo_rows;       // users whose select pass is repeated with the plain thresholds (build_neighbors)
     int32_t sym_tiles_n = 0;       // tiles per side the cached list was built for
     hipEvent_t ev_produced[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr}, ev_ready = nullptr;
     int32_t* pinned_cnt = nullptr;
@@ -473,8 +474,47 @@ void build_neighbors(knncf_handle* h, int32_t count) {
     }
     KN_HIP(hipStreamSynchronize(sc));
     KN_HIP(hipStreamSynchronize(sp));
-    // rows whose shortlist overflowed: exact row + stable descending sort (rare)
+    // select.hip anticipates its emission thresholds and marks a row whose guess overshot (like one whose stores overflowed)
+    // for the exact fallback below — a 7-sigma event per row when the dense user order is a pseudo-random column sample,
+    // which HashSet ranks of the raw ids are.  Should a data set defeat that (many rows marked), the marked rows are not sent
+    // through the per-row exact path (milliseconds each) but once more through select + re-rank with the plain thresholds:
+    // the anticipation can then cost at most one extra pass.  (Whole-matrix builds: the similarity panel is still there.)
     std::vector<int32_t> h_rows;
+    if (use_sym) {
+        std::vector<int32_t> marked;
+        for (int64_t r = 0; r < count; ++r)
+            if (h->pinned_cnt[r] > cap) marked.push_back((int32_t)r);
+        if ((int64_t)marked.size() > std::max<int64_t>(64, count / 200)) {
+            h_rows.resize(count);
+            KN_HIP(hipMemcpyAsync(h_rows.data(), h->build_list.p, (size_t)count * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            KN_HIP(hipStreamSynchronize(st));
+            std::vector<int32_t> users(marked.size());
+            for (size_t j = 0; j < marked.size(); ++j) users[j] = h_rows[marked[j]];
+            TailEntries te{h->te_cnt.p, h->te_item.p, h->te_x.p, h->row_tail_abs.p, h->row_head_sq.p, h->row_len.p};
+            h->redo_rows.ensure(std::min<int64_t>((int64_t)marked.size(), R));
+            for (size_t j0 = 0; j0 < marked.size(); j0 += (size_t)R) {  // (the shortlist / group stores hold R rows)
+                const int32_t m = (int32_t)std::min<size_t>((size_t)R, marked.size() - j0);
+                KN_HIP(hipMemcpyAsync(h->redo_rows.p, users.data() + j0, (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, st));
+                {
+                    Stage s(h, &h->tm.select_ms);
+                    launch_tail_select(tr, h->colmap.p, te, head < tr.I, h->S_full.p, true, s_fp16, U_pad, m, h->redo_rows.p, nt.k, eps_opnd, eps_rest, cap,
+                                       h->sel.cand_idx.p, h->sel.cand_approx.p, h->sel.cand_cnt.p, h->sel.cand_eps.p, h->sel.grp_v0.p, h->sel.grp_x.p,
+                                       select_gcap(nt.k), st, /*anticipate=*/false);
+                    h->tm.select_launches += 1;
+                }
+                {
+                    Stage s(h, &h->tm.rerank_ms);
+                    launch_rerank(tr, nt, m, h->redo_rows.p, cap, h->sel.cand_idx.p, h->sel.cand_approx.p, h->sel.cand_cnt.p, h->sel.cand_eps.p,
+                                  h->sel.stats.p, h->sel.row_entries.p, verify, st);
+                }
+                std::vector<int32_t> again(m);
+                KN_HIP(hipMemcpyAsync(again.data(), h->sel.cand_cnt.p, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+                KN_HIP(hipStreamSynchronize(st));
+                for (int32_t j = 0; j < m; ++j) h->pinned_cnt[marked[j0 + j]] = again[j];
+            }
+        }
+    }
+    // rows whose shortlist overflowed: exact row + stable descending sort (rare)
     for (int64_t r = 0; r < count; ++r) {
         h->tm.shortlist_total += std::min(h->pinned_cnt[r], cap);
         if (h->pinned_cnt[r] > cap) {

@@ -195,7 +195,9 @@ void launch_tail_entries(const Train& tr, const int32_t* d_colmap, int32_t* te_c
 void launch_tail_select(const Train& tr, const int32_t* d_colmap, const TailEntries& te, bool has_tail, const void* S, bool s_by_user, bool s_fp16, int64_t lds,
                         int32_t n_rows, const int32_t* d_row_user, int32_t k, float eps_opnd, float eps_rest, int32_t cap,
                         int32_t* cand_idx, float* cand_approx, int32_t* cand_cnt, float* cand_eps, int32_t* grp_v0, float* grp_x,
-                        int32_t gcap, hipStream_t st);
+                        int32_t gcap, hipStream_t st, bool anticipate = true);
+// (anticipate = false: the emission thresholds are the plain k-th largest value seen so far — api.cpp re-runs the rows of a
+// build whose anticipated thresholds overshot too often that way)
 // exact fp64 similarities of the shortlists in reference order, stable top-k
 void launch_rerank(const Train& tr, NeighborTable& nt, int32_t n_rows, const int32_t* d_row_user,
                    int32_t cap, const int32_t* cand_idx, const float* cand_approx,

@@ -851,7 +851,7 @@ void select_profile_dump() {
 template <class ST, bool JAC>
 static void launch_tail_select_t(const TailArgs& T, const ST* S, bool s_by_user, int64_t lds, int32_t n_rows, const int32_t* d_row_user,
                                  int32_t U, int32_t kk, float eps_opnd, float eps_rest, int32_t cap, int32_t* cand_idx, float* cand_approx,
-                                 int32_t* cand_cnt, float* cand_eps, int32_t* grp_v0, float* grp_x, int32_t gcap, hipStream_t st) {
+                                 int32_t* cand_cnt, float* cand_eps, int32_t* grp_v0, float* grp_x, int32_t gcap, bool anticipate, hipStream_t st) {
     const size_t smem = (size_t)TCOLS * 4 + (size_t)NBINS * 4 + (size_t)EMAX * 4 + 2 * ((size_t)EMAX * 12 + (size_t)PMAX * 2) + (2 * (TPB / 64) + 4 + 64) * 4;  // + 64 scratch cells
     static PerDeviceState lds_state;
     ensure_dynamic_lds(lds_state, (const void*)k_tail_select<ST, JAC>, smem);
@@ -861,7 +861,7 @@ static void launch_tail_select_t(const TailArgs& T, const ST* S, bool s_by_user,
     const float ant_sigma = -1.0f;
 #else
     const char* sg = getenv("KNNCF_DEBUG_ANTICIPATE_SIGMA");
-    const float ant_sigma = sg ? (float)atof(sg) : 7.0f;
+    const float ant_sigma = !anticipate ? -1.0f : sg ? (float)atof(sg) : 7.0f;
 #endif
     k_tail_select<ST, JAC><<<n_rows, TPB, smem, st>>>(S, s_by_user ? 1 : 0, lds, n_rows, d_row_user, T, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, ant_sigma);
     KN_HIP(hipGetLastError());
@@ -874,7 +874,7 @@ static void launch_tail_select_t(const TailArgs& T, const ST* S, bool s_by_user,
 void launch_tail_select(const Train& tr, const int32_t* d_colmap, const TailEntries& te, bool has_tail, const void* S, bool s_by_user, bool s_fp16, int64_t lds,
                         int32_t n_rows, const int32_t* d_row_user, int32_t k, float eps_opnd, float eps_rest, int32_t cap,
                         int32_t* cand_idx, float* cand_approx, int32_t* cand_cnt, float* cand_eps, int32_t* grp_v0, float* grp_x,
-                        int32_t gcap, hipStream_t st) {
+                        int32_t gcap, hipStream_t st, bool anticipate) {
     if (n_rows <= 0) return;
     KN_REQUIRE(gcap >= 1024 && gcap % 8 == 0, KNNCF_E_INVALID, "select: group store too small");
     const int32_t U = tr.U;
@@ -890,11 +890,11 @@ void launch_tail_select(const Train& tr, const int32_t* d_colmap, const TailEntr
                te.cnt, te.item, te.x, te.tail_abs, te.head_sq, te.row_len};
     if (tr.jaccard) {
         KN_REQUIRE(te.row_len != nullptr, KNNCF_E_STATE, "select: row lengths missing");
-        if (s_fp16) launch_tail_select_t<_Float16, true>(T, static_cast<const _Float16*>(S), s_by_user, lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, st);
-        else launch_tail_select_t<float, true>(T, static_cast<const float*>(S), s_by_user, lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, st);
+        if (s_fp16) launch_tail_select_t<_Float16, true>(T, static_cast<const _Float16*>(S), s_by_user, lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, anticipate, st);
+        else launch_tail_select_t<float, true>(T, static_cast<const float*>(S), s_by_user, lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, anticipate, st);
     } else {
-        if (s_fp16) launch_tail_select_t<_Float16, false>(T, static_cast<const _Float16*>(S), s_by_user, lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, st);
-        else launch_tail_select_t<float, false>(T, static_cast<const float*>(S), s_by_user, lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, st);
+        if (s_fp16) launch_tail_select_t<_Float16, false>(T, static_cast<const _Float16*>(S), s_by_user, lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, anticipate, st);
+        else launch_tail_select_t<float, false>(T, static_cast<const float*>(S), s_by_user, lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, anticipate, st);
     }
 }
 

@@ -438,9 +438,11 @@ def test_wide_shape_takes_the_large_u_paths(kn, oracle, synth):
 
 def test_overshooting_anticipated_thresholds_are_caught(kn, synth, monkeypatch):
     """select.hip emits against ANTICIPATED thresholds (rank k f + 7 sigma ... of the columns seen) and verifies them at the
-    end of the row; with the margin cut to 1.5 sigma (test hook) the guess overshoots in some rows, the final check must
+    end of the row; with the margin cut to 2.5 sigma (test hook) the guess overshoots in some rows, the final check must
     notice, and those rows are rebuilt exactly: every neighbour list then still equals the default build's, which the
-    full-size and wide-shape tests pin to the oracle."""
+    full-size and wide-shape tests pin to the oracle.  With no margin at all the guess fails in a large part of the rows: the
+    host then sends the marked rows through select + re-rank once more with the plain thresholds instead of through the
+    per-row exact path (no fallback row is left)."""
     import torch
 
     d = synth.syn_scaled(90_000, 3_000, 3_000_000, seed=31, half_stars=True)   # six column tiles
@@ -448,7 +450,7 @@ def test_overshooting_anticipated_thresholds_are_caught(kn, synth, monkeypatch):
     tr = tuple(torch.from_numpy(a).to(dev) for a in (d.train.users, d.train.items, d.train.ratings))
     users = np.unique(d.train.users)
     out = {}
-    for sigma in (None, "1.5", "-1"):
+    for sigma in (None, "2.5", "0", "-1"):
         if sigma is None:
             monkeypatch.delenv("KNNCF_DEBUG_ANTICIPATE_SIGMA", raising=False)
         else:
@@ -458,11 +460,12 @@ def test_overshooting_anticipated_thresholds_are_caught(kn, synth, monkeypatch):
         ids, sims, counts = e.neighbors_batch(users)
         t = e.timings()
         assert t["max_bound_violation"] <= 0.0
-        out[sigma] = (ids, sims, counts, t["fallback_rows"])
+        out[sigma] = (ids, sims, counts, t["fallback_rows"], t["select_launches"])
         e.close()
     assert out[None][3] == 0 and out["-1"][3] == 0        # 7 sigma / no anticipation: no row needs the fallback
-    assert 0 < out["1.5"][3] < len(users) // 10           # the hook really produced overshoots, and not everywhere
-    for sigma in ("1.5", "-1"):
+    assert 0 < out["2.5"][3] < len(users) // 10           # the hook really produced overshoots, and not everywhere
+    assert out["0"][3] == 0 and out["0"][4] == out[None][4] + 1   # too many overshoots for the per-row path: one plain second pass
+    for sigma in ("2.5", "0", "-1"):
         assert np.array_equal(out[sigma][0], out[None][0]) and np.array_equal(out[sigma][2], out[None][2])
         assert np.array_equal(out[sigma][1].view(np.int64), out[None][1].view(np.int64))
 
