@@ -323,7 +323,10 @@ def main():
         }
         if world == 1 and not args.no_bf16_leg and not (args.engine_flags & 4):
             # north_star says bf16 operands; the default is fp16 (same MFMA rate, 8x narrower error band, identical
-            # results).  The bf16 number of the same build, outside the timed region:
+            # results).  The bf16 number of the same build, outside the timed region (the fp16 handle is closed first: two
+            # handles of this shape do not both fit the one-block configuration in 288 GB, and the leg should measure what a
+            # bf16 run of this command measures):
+            eng.close()
             eb = kn.Engine(k=args.k, similarity=kn.SIM_COSINE, device=dev_index, head_items=args.head_items,
                            flags=args.engine_flags | kn.FLAG_BF16_FILTER)
             mb = sharded.ShardedKnn(sharded.DeviceEngineAdapter(eb, device), None, 0, 1)

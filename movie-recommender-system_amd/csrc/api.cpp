@@ -309,8 +309,13 @@ void build_neighbors(knncf_handle* h, int32_t count) {
     // 288 GB of HBM hold it easily at the ml-25m shape (53 GB as fp16); shapes whose square does not fit (syn-1M: 2 TB)
     // and partial / sharded builds take the row-block path.
     const size_t sym_bytes = (size_t)U_pad * (size_t)U_pad * (size_t)s_elem;
+    // (what this handle already holds counts as free: the decision must not flip between two builds of the same shape because
+    // the first one allocated — measured: a handle built beside another one's 135 GB sat exactly on the edge, released the
+    // 53 GB panel in its second build and spent 1.5 s re-allocating)
+    size_t own = h->S_full.bytes() + h->sel.cand_idx.bytes() + h->sel.cand_approx.bytes() + h->sel.grp_v0.bytes() + h->sel.grp_x.bytes();
+    for (int s = 0; s < 2; ++s) own += h->S[s].bytes() + h->Apanel[s].bytes();
     bool use_sym = h->cfg.shard_count == 1 && (int64_t)count * 2 >= tr.U && U_pad / 256 < 65536 &&
-                   sym_bytes <= (free_b + h->S_full.bytes()) / 3 && !getenv("KNNCF_DEBUG_NO_SYMMETRIC_GEMM");
+                   sym_bytes <= (free_b + own) / 3 && !getenv("KNNCF_DEBUG_NO_SYMMETRIC_GEMM");
     if (use_sym) {
         try {
             h->S_full.ensure((sym_bytes + 3) / 4);
