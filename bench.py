@@ -133,6 +133,9 @@ def main():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1: nccl (= RCCL, the product path) or gloo "
                     "(rehearsal of the N > 1 host path with several ranks sharing one GPU; collectives staged through the host)")
+    ap.add_argument("--force-process-group", action="store_true", help="run the whole collective protocol (process group init with device_id, "
+                    "the padded all-gather of the (mean, norm) segments, the collective status, the MAE all-reduce, destroy) even at "
+                    "--gpus 1: the one-rank rehearsal of the RCCL path on a single MI355X (tests/test_bench_ranks.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16-leg", action="store_true", help="skip the extra (untimed) bf16-operand steps reported beside the fp16 default")
     ap.add_argument("--head-items", type=int, default=0, help="dense head width of the hybrid similarity (0 = cost model)")
@@ -154,10 +157,13 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_process_group:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=device)  # nccl == RCCL on ROCm
         else:
@@ -184,7 +190,7 @@ def main():
 
     eng = kn.Engine(k=args.k, similarity=kn.SIM_COSINE, device=dev_index, shard_rank=rank, shard_count=world,
                     head_items=args.head_items, flags=args.engine_flags, workspace_bytes=args.workspace_bytes)
-    model = sharded.ShardedKnn(sharded.DeviceEngineAdapter(eng, device), dist, rank, world)
+    model = sharded.ShardedKnn(sharded.DeviceEngineAdapter(eng, device), dist, rank, world, collective=dist is not None)
 
     def step():
         model.fit(*d_tr)  # closures are rebuilt every measurement, like the reference's timed region
@@ -307,7 +313,10 @@ def main():
                        # one step = knncf_fit + knncf_mae(PRED_KNN): what predict/kNN.scala:43-57 evaluates.  The per-item maps of the
                        # baseline predictors (K4: itemsAvg, itemsAvgDev) are not on that path in the reference either (predictions.scala
                        # :489-585 never calls them); the handle builds them on first use
-                       "step": "fit (K0-K3) + neighbourhoods (K5, K6) + predictions + MAE (K7, K8); K4 not on the kNN path"},
+                       "step": "fit (K0-K3) + neighbourhoods (K5, K6) + predictions + MAE (K7, K8); K4 not on the kNN path",
+                       "collectives": (f"torch.distributed/{dist.get_backend()} ({'RCCL' if dist.get_backend() == 'nccl' else 'host-staged rehearsal'}), "
+                                       f"world {world}: all-gather of the per-user (mean, norm) segments, all-reduce of the fit status and of "
+                                       f"(sum |err|, rows, status)") if dist is not None else "none (one handle)"},
             "roofline": kernels[dominant],  # the dominant kernel of THIS run (by summed launch time)
             "roofline_all": kernels,
             "stage_ms_per_step": {k_: tm[k_] / steps for k_ in ("prep_ms", "densify_ms", "gemm_ms", "tail_ms", "select_ms", "rerank_ms", "predict_ms")},

@@ -177,10 +177,17 @@ int knncf_mae_device(knncf_handle* h, int predictor, const int32_t* d_users,
                      double* sum_abs_err, int64_t* count, double* d_pred);
 
 /* ---- multi-GPU exchange (one handle per GPU, collectives done by the host) - */
-/* After knncf_fit* on every shard, each shard holds the per-user means/norms
- * and the per-rating deviations of ITS users only.  The host all-gathers the
- * segments below (RCCL all-gather over xGMI) in place, then calls
- * knncf_shard_commit.  With shard_count == 1 these are no-ops. */
+/* After knncf_fit* on every shard, each shard holds the per-user means / norms
+ * (the order-sensitive fp64 folds of K2 / K3) of ITS users only.  The host
+ * all-gathers d_user_avg[user_begin, user_end) and d_user_norm[...] (RCCL
+ * all-gather over xGMI: 16 B per user) in place, then calls knncf_shard_commit,
+ * which recomputes the other users' normalized deviations and preprocessed
+ * ratings — elementwise functions of (rating, mean) and (deviation, norm) — bit
+ * for bit, so nothing per RATING travels.  (d_dev / d_pre stay in the view: a host
+ * that gathers them as well, as the round-1 protocol did, gets the same values
+ * written twice.)  Users are block-partitioned in ascending dense order,
+ * ceil(num_users / shard_count) per shard.  With shard_count == 1 these are no-ops.
+ * One process driving all GPUs binds knncf_group_* below instead. */
 typedef struct knncf_shard_view {
     int32_t user_begin, user_end; /* owned dense users [begin, end) */
     int64_t nnz_begin, nnz_end;   /* their entries in the user-major rating arrays */
@@ -193,6 +200,33 @@ typedef struct knncf_shard_view {
 } knncf_shard_view;
 int knncf_shard_view_get(knncf_handle* h, knncf_shard_view* out);
 int knncf_shard_commit(knncf_handle* h);
+
+/* ---- one process, several GPUs: the collectives inside the library ---------- */
+/* A group = n shard handles (shard_rank i on devices[i]) + one RCCL communicator per device (ncclCommInitAll) + one
+ * HIP stream per device for the collectives; every entry point drives the n GPUs from n host threads.  This is what a
+ * JVM binds: ONE call per step instead of a re-implementation of the exchange —
+ * distributed/DistributedBaseline.scala:41-47 hands one RDD to Spark the same way.
+ *   knncf_group_fit  : knncf_fit on every shard (the host arrays are copied to every device) -> collective status ->
+ *                      ncclAllGather of the padded {mean, norm} segments -> knncf_shard_commit on every shard.
+ *   knncf_group_mae  : knncf_mae_device on every shard (each predicts the test rows of its own users) -> collective
+ *                      status -> ncclAllReduce (sum) of (sum |r - p|, rows) -> mae; shared/predictions.scala:246-268's
+ *                      `sum` / `count` actions.
+ * cfg->device, shard_rank and shard_count are ignored (the group sets them).  RCCL is loaded at the first
+ * knncf_group_create (dlopen of librccl.so.1: the library itself does not link it); KNNCF_E_UNSUPPORTED if it is absent,
+ * KNNCF_E_RCCL for a failing RCCL call.  A group is not thread-safe. */
+#define KNNCF_E_RCCL (-9)
+typedef struct knncf_group knncf_group;
+int knncf_group_create(const knncf_config* cfg, const int32_t* devices, int32_t n_devices, knncf_group** out);
+void knncf_group_destroy(knncf_group* g);
+const char* knncf_group_last_error(const knncf_group* g);
+int knncf_group_size(const knncf_group* g, int32_t* n_devices);
+/* the shard handle of rank i (owned by the group): scalar queries, knncf_neighbors of ITS users, timings */
+int knncf_group_handle(knncf_group* g, int32_t rank, knncf_handle** out);
+int knncf_group_fit(knncf_group* g, const int32_t* users, const int32_t* items, const double* ratings, int64_t n);
+int knncf_group_mae(knncf_group* g, int predictor, const int32_t* users, const int32_t* items, const double* ratings,
+                    int64_t n, double* mae);
+/* every shard predicts the rows of its own users; out[0..n) receives all of them */
+int knncf_group_predict_batch(knncf_group* g, int predictor, const int32_t* users, const int32_t* items, int64_t n, double* out);
 
 /* ---- loader and on-disk cache --------------------------------- */
 /* `load` shared/predictions.scala:35-49 as a multithreaded host parser: the line is split on `separator` (literal),

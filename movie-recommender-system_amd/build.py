@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "obj")
 LIB = os.path.join(HERE, "libknncf.so")
 CLI = os.path.join(HERE, "knncf")
-SOURCES = ["api.cpp", "loader.cpp", "prep.hip", "sort_util.hip", "gemm.hip", "select.hip", "rerank.hip", "predict.hip", "neighbours.hip", "reco.hip"]
+SOURCES = ["api.cpp", "group.cpp", "loader.cpp", "prep.hip", "sort_util.hip", "gemm.hip", "select.hip", "rerank.hip", "predict.hip", "neighbours.hip", "reco.hip"]
 HEADERS = ["common.h", "engine.h", os.path.join("..", "..", "include", "knncf.h")]
 # -ffp-contract=off: the fp64 kernels must round exactly like the reference's JVM arithmetic (no FMA)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
@@ -56,7 +56,7 @@ def build(force=False, verbose=False):
                 print(warn, file=sys.stderr)
     objs = [os.path.join(OBJ, os.path.splitext(s)[0] + ".o") for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

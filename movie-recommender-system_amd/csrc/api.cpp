@@ -17,8 +17,8 @@ namespace knncf {
 void launch_first_rows(int64_t n, const int32_t* d_du, const int32_t* d_di, int32_t own_lo, int32_t own_hi,
                        uint32_t* d_first, hipStream_t st);
 void launch_length_keys(int32_t count, const int32_t* d_list, const int64_t* d_u_ptr, int32_t max_len, uint64_t* d_key, hipStream_t st);
-void launch_collect_new(int32_t U, const uint32_t* d_first, int64_t* d_seq, int64_t epoch, int32_t* d_list,
-                        int32_t* d_count, hipStream_t st);
+void launch_collect_new(int32_t U, const uint32_t* d_first, int64_t* d_seq, int64_t epoch, int32_t own_lo, int32_t own_hi,
+                        int32_t* d_list, int32_t* d_count, hipStream_t st);
 void launch_fallback_keys(int32_t U, const double* d_exact, uint64_t* d_keys, uint32_t* d_vals, hipStream_t st);
 void launch_fallback_write(int32_t user, int32_t take, int32_t kcap, const uint32_t* d_sorted_vals,
                            const double* d_exact, int32_t* nbr_idx, double* nbr_sim, int32_t* nbr_cnt,
@@ -578,8 +578,9 @@ void ensure_neighbors_for_rows(knncf_handle* h, int64_t n) {
     h->build_count.ensure(1);
     KN_HIP(hipMemsetAsync(h->first_row.p, 0xff, tr.U * sizeof(uint32_t), st));
     KN_HIP(hipMemsetAsync(h->build_count.p, 0, sizeof(int32_t), st));
-    launch_first_rows(n, h->t_du.p, h->t_di.p, tr.own_lo, tr.own_hi, h->first_row.p, st);
-    launch_collect_new(tr.U, h->first_row.p, h->nt.seq.p, h->epoch, h->build_list.p, h->build_count.p, st);
+    // (every user's first row, whoever owns it: a shard needs the build sequence numbers of the other shards' users too)
+    launch_first_rows(n, h->t_du.p, h->t_di.p, 0, tr.U, h->first_row.p, st);
+    launch_collect_new(tr.U, h->first_row.p, h->nt.seq.p, h->epoch, tr.own_lo, tr.own_hi, h->build_list.p, h->build_count.p, st);
     h->epoch += 1;
     int32_t count = fetch(h, h->build_count.p, 0);
     build_neighbors(h, count);
@@ -881,6 +882,7 @@ const char* knncf_status_string(int st) {
         case KNNCF_E_STATE: return "invalid call order";
         case KNNCF_E_UNSUPPORTED: return "unsupported configuration";
         case KNNCF_E_NODEVICE: return "no usable gfx950 device";
+        case KNNCF_E_RCCL: return "RCCL error";
         default: return "unknown status";
     }
 }
@@ -1262,6 +1264,7 @@ int knncf_shard_commit(knncf_handle* h) {
         require_fitted(h, false);
         if (h->committed) return;
         Stage s(h, &h->tm.prep_ms);
+        if (h->cfg.shard_count > 1) prep_complete_rows(h->tr, h->prep, h->stream);
         prep_commit(h->tr, h->prep, h->stream);
         h->committed = true;
     });

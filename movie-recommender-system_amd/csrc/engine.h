@@ -83,13 +83,14 @@ struct Train {
     std::vector<int64_t> pop_count;  // host: rater counts in that order
     double global_avg = 0.0;
     int32_t own_lo = 0, own_hi = 0;  // owned dense users [lo, hi)
+    int64_t own_p0 = 0, own_p1 = 0;  // their positions in the canonical order (everything when not sharded)
     // the handle's similarity is jaccardCoefficient :440-464: the similarity stage then counts common items — 0/1 operand
     // panels, tail entries of value 1 — instead of summing products of preprocessed ratings
     bool jaccard = false;
 };
 
 // status word bits written by kernels
-enum : uint32_t { ST_NONFINITE = 1u, ST_DUPLICATE = 2u, ST_NOT_DYADIC = 4u, ST_SMALL_ROW = 8u, ST_LONG_ROW = 16u };
+enum : uint32_t { ST_NONFINITE = 1u, ST_DUPLICATE = 2u, ST_NOT_DYADIC = 4u, ST_LONG_ROW = 16u };
 
 struct PrepScratch {
     SortWorkspace sort;
@@ -121,6 +122,10 @@ struct PrepScratch {
 
 // K0 + K1 + owned part of K2/K3.  Throws Error on invalid data.
 void prep_fit(Train& tr, PrepScratch& sc, int32_t shard_rank, int32_t shard_count, hipStream_t st);
+// sharded handles, after the exchange of the per-user (mean, norm): the deviations and preprocessed ratings of the users
+// this shard does NOT own — pure elementwise functions of (rating, the user's mean) and (deviation, the user's norm), so
+// every rank recomputes them bit for bit instead of receiving 16 B per rating over xGMI
+void prep_complete_rows(Train& tr, PrepScratch& sc, hipStream_t st);
 // item-major copies, rater bitmaps, popularity order (need every user's deviations: after the shards' exchange)
 void prep_commit(Train& tr, PrepScratch& sc, hipStream_t st);
 // K4: the per-item statistics of the baseline predictors (after prep_commit; sets tr.item_stats_ready)

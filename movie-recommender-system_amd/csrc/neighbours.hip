@@ -38,18 +38,21 @@ void launch_first_rows(int64_t n, const int32_t* d_du, const int32_t* d_di, int3
 
 // users that need a neighbourhood now; their build sequence number orders them like the
 // reference's memo history: (call epoch, first test row)
+// Sharded handles: EVERY user gets its sequence number (the test rows are replicated on every shard, so every shard
+// derives the same numbers with no exchange — rerank.hip: pair_sim needs seq[v] of users another shard builds), but
+// only the owned users [own_lo, own_hi) are listed for building.
 __global__ void k_collect_new(int32_t U, const uint32_t* __restrict__ first, int64_t* __restrict__ seq, int64_t epoch,
-                              int32_t* __restrict__ list, int32_t* __restrict__ count) {
+                              int32_t own_lo, int32_t own_hi, int32_t* __restrict__ list, int32_t* __restrict__ count) {
     int32_t u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= U) return;
     if (first[u] == 0xffffffffu || seq[u] >= 0) return;
     seq[u] = (epoch << 32) | (int64_t)first[u];
-    list[atomicAdd(count, 1)] = u;
+    if (u >= own_lo && u < own_hi) list[atomicAdd(count, 1)] = u;
 }
 
-void launch_collect_new(int32_t U, const uint32_t* d_first, int64_t* d_seq, int64_t epoch, int32_t* d_list,
-                        int32_t* d_count, hipStream_t st) {
-    k_collect_new<<<(unsigned)ceil_div(U, TPB), TPB, 0, st>>>(U, d_first, d_seq, epoch, d_list, d_count);
+void launch_collect_new(int32_t U, const uint32_t* d_first, int64_t* d_seq, int64_t epoch, int32_t own_lo, int32_t own_hi,
+                        int32_t* d_list, int32_t* d_count, hipStream_t st) {
+    k_collect_new<<<(unsigned)ceil_div(U, TPB), TPB, 0, st>>>(U, d_first, d_seq, epoch, own_lo, own_hi, d_list, d_count);
     KN_HIP(hipGetLastError());
 }
 

@@ -634,8 +634,14 @@ __global__ void k_owned_keys(int64_t n, const int32_t* __restrict__ src, const i
         key[t] = !mine ? (uint64_t)limit + 1ull : (src[t] < 0 ? (uint64_t)limit : (uint64_t)(uint32_t)src[t]);
         val[t] = (uint32_t)t;
     }
+    // one atomic per BLOCK: 5 M rows / 64 same-address atomics serialise in the L2 (0.34 ms at the ml-25m shape)
+    __shared__ unsigned int block_owned;
+    if (threadIdx.x == 0) block_owned = 0;
+    __syncthreads();
     const unsigned long long b = __ballot(mine);
-    if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_owned, (unsigned long long)__popcll(b));
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&block_owned, (unsigned int)__popcll(b));
+    __syncthreads();
+    if (threadIdx.x == 0 && block_owned) atomicAdd(n_owned, (unsigned long long)block_owned);
 }
 
 void launch_owned_keys(int64_t n, const int32_t* d_src, const int32_t* d_du, int32_t own_lo, int32_t own_hi, bool unknown_owned, uint32_t limit,

@@ -491,13 +491,6 @@ __global__ void k_segment_ptr_u32(int64_t n, const uint32_t* __restrict__ sorted
     ptr[s] = lo;
 }
 
-// a user with <= 4 ratings: its item set is a Set1..Set4 (insertion order), and which order a pair's similarity is summed in
-// then depends on the closures' evaluation history
-__global__ void k_flag_small_rows(int32_t U, const int64_t* __restrict__ u_ptr, uint32_t* __restrict__ status) {
-    const int32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u < U && u_ptr[u + 1] - u_ptr[u] <= 4) atomicOr(status, (uint32_t)ST_SMALL_ROW);
-}
-
 __global__ void k_iota(int64_t n, uint32_t* __restrict__ v) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n) v[t] = (uint32_t)t;
@@ -841,6 +834,8 @@ void prep_fit(Train& tr, PrepScratch& sc, int32_t shard_rank, int32_t shard_coun
         p0 = hp[0];
         p1 = hp[1];
     }
+    tr.own_p0 = p0;
+    tr.own_p1 = p1;
     // (KNNCF_DEBUG_GLOBAL_HASH_ORDER: test hook, forces the global sorts that a user with more than SEG_BLOCK_CAP ratings takes)
     const bool seg_sorts = max_len <= (uint32_t)SEG_BLOCK_CAP && !getenv("KNNCF_DEBUG_GLOBAL_HASH_ORDER");
     sc.long_rows.ensure(2 * (size_t)U + 2);
@@ -940,16 +935,12 @@ void prep_fit(Train& tr, PrepScratch& sc, int32_t shard_rank, int32_t shard_coun
     tr.item_stats_ready = false;
 
     // K1: average :94 — left fold over the file; exact in any order for dyadic ratings
-    if (shard_count > 1) k_flag_small_rows<<<nblocks(tr.U), TPB, 0, st>>>(tr.U, tr.u_ptr.p, sc.status.p);
-    KN_HIP(hipGetLastError());
     uint32_t status = read_status(sc, st);
     KN_REQUIRE(!(status & ST_DUPLICATE), KNNCF_E_DUPLICATE, "fit: duplicate (user,item) training rows");
     KN_REQUIRE(!(status & ST_LONG_ROW), KNNCF_E_STATE, "fit: a row longer than the segment sorts take reached them");
-    // The summation order of a pair with a <= 4-rating user follows the memo history of the reference's closures; a single
-    // handle models it (nbr_seq), but the shards do not exchange their build sequence numbers: refused rather than
-    // answered differently from the single-GPU run.  Every rank holds all rows, so every rank refuses alike.
-    KN_REQUIRE(!(status & ST_SMALL_ROW), KNNCF_E_UNSUPPORTED,
-               "fit: a user with <= 4 ratings in a sharded fit (the result would depend on cross-shard evaluation order, SURVEY N6); fit it on one handle");
+    // (A pair with a <= 4-rating user is summed in the order of whichever closure evaluated it first, SURVEY N6.  Sharded
+    // handles follow that history too: the test set is replicated, so every shard assigns EVERY user its build sequence
+    // number — api.cpp: ensure_neighbors_for_rows — and rerank.hip applies the owner rule with no exchange.)
     sc.dsum.ensure(2);
     KN_HIP(hipMemsetAsync(sc.dsum.p, 0, 2 * sizeof(double), st));
     if (status & ST_NOT_DYADIC) k_sequential_sum<<<1, TPB, 0, st>>>(n, tr.rating.p, sc.dsum.p);
@@ -961,11 +952,10 @@ void prep_fit(Train& tr, PrepScratch& sc, int32_t shard_rank, int32_t shard_coun
     tr.global_avg = total / (double)n;
 
     tr.user_avg.alloc(U); tr.user_norm.alloc(U);
-    if (shard_count > 1) {  // the host all-gathers the other shards' segments in place
+    if (shard_count > 1) {  // the host all-gathers the other shards' (mean, norm) segments in place; prep_complete_rows then
+                            // fills in the other users' deviations and preprocessed ratings
         KN_HIP(hipMemsetAsync(tr.user_avg.p, 0, U * sizeof(double), st));
         KN_HIP(hipMemsetAsync(tr.user_norm.p, 0, U * sizeof(double), st));
-        KN_HIP(hipMemsetAsync(tr.s_dev.p, 0, n * sizeof(double), st));
-        KN_HIP(hipMemsetAsync(tr.s_pre.p, 0, n * sizeof(double), st));
     }
     if (hi > lo) {
         // K2: usersAvg :113 (groupBy keeps file order; mean = reduce(_+_) / length)
@@ -981,6 +971,20 @@ void prep_fit(Train& tr, PrepScratch& sc, int32_t shard_rank, int32_t shard_coun
     status = read_status(sc, st);
     KN_REQUIRE(!(status & ST_NONFINITE), KNNCF_E_NONFINITE,
                "fit: non-finite normalized deviation (a user's mean is 1 or 5 with a rating beyond it: scale() == 0)");
+}
+
+void prep_complete_rows(Train& tr, PrepScratch& sc, hipStream_t st) {
+    const int64_t p0 = tr.own_p0, p1 = tr.own_p1, n = tr.n;
+    // (a non-finite deviation among another shard's users failed that shard's fit already; the status word is not re-read)
+    if (p0 > 0) {
+        k_deviation<<<nblocks(p0), TPB, 0, st>>>(0, p0, tr.s_user.p, tr.s_rating.p, tr.user_avg.p, tr.s_dev.p, sc.status.p);
+        k_preprocess<<<nblocks(p0), TPB, 0, st>>>(0, p0, tr.s_user.p, tr.s_dev.p, tr.user_norm.p, tr.s_pre.p);
+    }
+    if (p1 < n) {
+        k_deviation<<<nblocks(n - p1), TPB, 0, st>>>(p1, n, tr.s_user.p, tr.s_rating.p, tr.user_avg.p, tr.s_dev.p, sc.status.p);
+        k_preprocess<<<nblocks(n - p1), TPB, 0, st>>>(p1, n, tr.s_user.p, tr.s_dev.p, tr.user_norm.p, tr.s_pre.p);
+    }
+    KN_HIP(hipGetLastError());
 }
 
 // item-major (item, user ascending) copies: (user, preprocessed rating) for the sparse tail of the similarity,

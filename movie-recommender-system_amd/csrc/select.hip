@@ -107,11 +107,11 @@ struct TailArgs {
 
 // one wave per user: the row's tail entries (colmap < 0) in position order, compacted to the front of the row's range; the
 // sums in a fixed order (position -> lane, then xor shuffles), so that the error band is the same on every run
-__global__ void k_tail_entries(int32_t U, const int64_t* __restrict__ u_ptr, const int32_t* __restrict__ s_col,
+__global__ void k_tail_entries(int32_t u_lo, int32_t U, const int64_t* __restrict__ u_ptr, const int32_t* __restrict__ s_col,
                                const double* __restrict__ s_pre, const int32_t* __restrict__ colmap, int32_t* __restrict__ te_cnt,
                                int32_t* __restrict__ te_item, float* __restrict__ te_x, float* __restrict__ row_tail_abs,
                                float* __restrict__ row_head_sq, int ones) {
-    const int32_t u = (int32_t)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int32_t u = u_lo + (int32_t)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int lane = threadIdx.x & 63;
     if (u >= U) return;
     const int64_t ub = u_ptr[u], ue = u_ptr[u + 1];
@@ -149,10 +149,13 @@ __global__ void k_tail_entries(int32_t U, const int64_t* __restrict__ u_ptr, con
     }
 }
 
+// (only the owned users' rows are ever selected from: a shard builds the lists of its own users)
 void launch_tail_entries(const Train& tr, const int32_t* d_colmap, int32_t* te_cnt, int32_t* te_item, float* te_x,
                          float* row_tail_abs, float* row_head_sq, hipStream_t st) {
-    k_tail_entries<<<(unsigned)ceil_div((int64_t)tr.U * 64, 256), 256, 0, st>>>(tr.U, tr.u_ptr.p, tr.s_col.p, tr.s_pre.p, d_colmap, te_cnt,
-                                                                                te_item, te_x, row_tail_abs, row_head_sq, tr.jaccard ? 1 : 0);
+    const int32_t lo = tr.own_lo, hi = tr.own_hi;
+    if (hi <= lo) return;
+    k_tail_entries<<<(unsigned)ceil_div((int64_t)(hi - lo) * 64, 256), 256, 0, st>>>(lo, hi, tr.u_ptr.p, tr.s_col.p, tr.s_pre.p, d_colmap, te_cnt,
+                                                                                     te_item, te_x, row_tail_abs, row_head_sq, tr.jaccard ? 1 : 0);
     KN_HIP(hipGetLastError());
 }
 

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libknncf.so")
 
 OK = 0
-E_INVALID, E_NONFINITE, E_DUPLICATE, E_NOMEM, E_HIP, E_STATE, E_UNSUPPORTED, E_NODEVICE = range(-1, -9, -1)
+E_INVALID, E_NONFINITE, E_DUPLICATE, E_NOMEM, E_HIP, E_STATE, E_UNSUPPORTED, E_NODEVICE, E_RCCL = range(-1, -10, -1)
 SIM_COSINE, SIM_ONE, SIM_JACCARD = 0, 1, 2
 PRED_GLOBAL_AVG, PRED_USER_AVG, PRED_ITEM_AVG, PRED_BASELINE, PRED_BASELINE_RDD, PRED_KNN, PRED_PERSONALIZED = range(7)
 FLAG_VERIFY_BOUND = 1
@@ -119,6 +119,8 @@ EXPORTS = [
     "knncf_predict_batch_device", "knncf_mae", "knncf_mae_device", "knncf_shard_view_get",
     "knncf_shard_commit", "knncf_get_timings", "knncf_reset_timings", "knncf_reset_neighbors",
     "knncf_set_k", "knncf_load_file", "knncf_load_file_cached", "knncf_free_ratings", "knncf_load_personal", "knncf_free_personal", "knncf_neighbors_save", "knncf_neighbors_load",
+    "knncf_group_create", "knncf_group_destroy", "knncf_group_last_error", "knncf_group_size", "knncf_group_handle",
+    "knncf_group_fit", "knncf_group_mae", "knncf_group_predict_batch",
 ]
 
 
@@ -148,6 +150,16 @@ def _share_hip_runtime_with_torch():
                 C.CDLL(path, mode=C.RTLD_GLOBAL)
             except OSError:
                 pass
+
+
+def _share_rccl_with_torch():
+    """knncf_group_* resolves RCCL at run time and reuses a copy that is already in the process.  Under Python that must
+    be the one PyTorch bundles (built against the HIP runtime _share_hip_runtime_with_torch bound the library to): load it
+    — importing torch does — before the first group is created, so that /opt/rocm's copy is not pulled in beside it."""
+    import importlib.util
+
+    if importlib.util.find_spec("torch") is not None:
+        import torch  # noqa: F401  (libtorch_hip links librccl)
 
 
 def load_library():
@@ -203,6 +215,16 @@ def load_library():
     L.knncf_free_personal.restype = None
     L.knncf_neighbors_save.argtypes = [C.c_void_p, C.c_char_p]
     L.knncf_neighbors_load.argtypes = [C.c_void_p, C.c_char_p]
+    L.knncf_group_create.argtypes = [C.POINTER(Config), _i32p, C.c_int32, C.POINTER(C.c_void_p)]
+    L.knncf_group_destroy.argtypes = [C.c_void_p]
+    L.knncf_group_destroy.restype = None
+    L.knncf_group_last_error.argtypes = [C.c_void_p]
+    L.knncf_group_last_error.restype = C.c_char_p
+    L.knncf_group_size.argtypes = [C.c_void_p, _i32p]
+    L.knncf_group_handle.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
+    L.knncf_group_fit.argtypes = [C.c_void_p, _i32p, _i32p, _f64p, C.c_int64]
+    L.knncf_group_mae.argtypes = [C.c_void_p, C.c_int, _i32p, _i32p, _f64p, C.c_int64, _f64p]
+    L.knncf_group_predict_batch.argtypes = [C.c_void_p, C.c_int, _i32p, _i32p, C.c_int64, _f64p]
     _lib = L
     return L
 
@@ -410,3 +432,65 @@ class Engine:
     def set_k(self, k):
         self._check(self._lib.knncf_set_k(self._h, k))
         self.k = k
+
+
+class Group:
+    """knncf_group_*: one process, several GPUs — n shard handles + RCCL communicators (ncclCommInitAll) inside the library;
+    fit = every shard's fit + ncclAllGather of the (mean, norm) segments + commit, mae = every shard's partial sums +
+    ncclAllReduce.  What a JVM binds; here the ctypes mirror for the tests."""
+
+    def __init__(self, devices, k=300, similarity=SIM_COSINE, flags=0, head_items=0, workspace_bytes=0):
+        self._lib = load_library()
+        _share_rccl_with_torch()
+        devs = _i32(devices)
+        cfg = Config(C.sizeof(Config), 0, k, similarity, 0, 1, workspace_bytes, flags, head_items)
+        g = C.c_void_p()
+        st = self._lib.knncf_group_create(C.byref(cfg), devs.ctypes.data_as(_i32p), len(devs), C.byref(g))
+        if st != OK:
+            raise KnncfError(st, self._lib.knncf_status_string(st).decode())
+        self._g = g
+        self.k = k
+        self.size = len(devs)
+
+    def close(self):
+        if getattr(self, "_g", None):
+            self._lib.knncf_group_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st != OK:
+            raise KnncfError(st, self._lib.knncf_group_last_error(self._g).decode())
+
+    def fit(self, users, items, ratings):
+        u, i, r = _i32(users), _i32(items), _f64(ratings)
+        self._check(self._lib.knncf_group_fit(self._g, u.ctypes.data_as(_i32p), i.ctypes.data_as(_i32p), r.ctypes.data_as(_f64p), len(u)))
+        return self
+
+    def mae(self, predictor, users, items, ratings):
+        u, i, r = _i32(users), _i32(items), _f64(ratings)
+        v = C.c_double()
+        self._check(self._lib.knncf_group_mae(self._g, predictor, u.ctypes.data_as(_i32p), i.ctypes.data_as(_i32p),
+                                              r.ctypes.data_as(_f64p), len(u), C.byref(v)))
+        return v.value
+
+    def predict_batch(self, predictor, users, items):
+        u, i = _i32(users), _i32(items)
+        out = np.empty(len(u), dtype=np.float64)
+        self._check(self._lib.knncf_group_predict_batch(self._g, predictor, u.ctypes.data_as(_i32p), i.ctypes.data_as(_i32p),
+                                                        len(u), out.ctypes.data_as(_f64p)))
+        return out
+
+    def shard(self, rank):
+        """the shard handle of `rank` as a borrowed Engine (queries, timings); owned by the group"""
+        h = C.c_void_p()
+        self._check(self._lib.knncf_group_handle(self._g, rank, C.byref(h)))
+        e = Engine.__new__(Engine)
+        e._lib, e._h, e.device, e.k = self._lib, h, None, self.k
+        e.close = lambda: None  # borrowed
+        return e

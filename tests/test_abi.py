@@ -15,13 +15,13 @@ def _declared():
 
 def test_library_exports_every_declared_symbol(pkg):
     build = importlib.import_module(pkg.__name__ + ".build")
-    lib_path = build.build()
-    lib = ctypes.CDLL(lib_path)
+    build.build()
+    kn = importlib.import_module(pkg.__name__ + ".knncf")
+    lib = kn.load_library()  # (the package's loader: it binds the library to the HIP runtime PyTorch bundles, one per process)
     names = _declared()
     assert len(names) >= 25
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/knncf.h but not exported"
-    kn = importlib.import_module(pkg.__name__ + ".knncf")
     assert sorted(kn.EXPORTS) == names
 
 
@@ -40,3 +40,20 @@ def test_status_strings_and_create_without_gpu(pkg):
             assert e.status == kn.E_NODEVICE
         else:
             raise AssertionError("Engine() must fail without a gfx950 device")
+
+
+def test_group_create_fails_loudly_without_gpu(pkg):
+    """knncf_group_*: the exports exist, and without a device (or without librccl) creation fails with a status — no
+    fallback path forms a "group" on the CPU"""
+    import torch
+
+    kn = importlib.import_module(pkg.__name__ + ".knncf")
+    kn.load_library()
+    if torch.cuda.is_available():
+        return
+    try:
+        kn.Group([0], k=3)
+    except kn.KnncfError as e:
+        assert e.status in (kn.E_NODEVICE, kn.E_UNSUPPORTED)
+    else:
+        raise AssertionError("Group() must fail without a gfx950 device")

@@ -60,8 +60,14 @@ class OracleShardEngine:
         return self.t
 
     def shard_commit(self):
-        for k in ("user_avg", "user_norm", "dev", "pre"):  # the exchange must have filled every segment
+        for k in ("user_avg", "user_norm"):  # the exchange must have filled every user's mean and norm
             np.testing.assert_array_equal(self.t[k].numpy(), self.full[k])
+        # knncf_shard_commit recomputes the other users' deviations / preprocessed ratings from them (prep_complete_rows)
+        own = np.zeros(len(self.full["dev"]), dtype=bool)
+        own[self.nlo:self.nhi] = True
+        for k in ("dev", "pre"):
+            assert not self.t[k].numpy()[~own].any()   # nothing of them travelled
+            self.t[k].numpy()[~own] = self.full[k][~own]
         self.committed = True
 
     def mae_device(self, predictor, users, items, ratings):
@@ -82,17 +88,22 @@ class PoisonedEngine(OracleShardEngine):
     class Boom(RuntimeError):
         status = -2  # KNNCF_E_NONFINITE
 
-    def __init__(self, oracle, rank, world, k, bad_rank):
+    def __init__(self, oracle, rank, world, k, bad_rank, where="fit"):
         super().__init__(oracle, rank, world, k)
-        self.bad_rank = bad_rank
+        self.bad_rank, self.where = bad_rank, where
 
     def fit_device(self, users, items, ratings):
-        if self.rank == self.bad_rank:
+        if self.rank == self.bad_rank and self.where == "fit":
             raise PoisonedEngine.Boom("non-finite normalized deviation")
         super().fit_device(users, items, ratings)
 
+    def mae_device(self, predictor, users, items, ratings):
+        if self.rank == self.bad_rank and self.where == "mae":  # e.g. KNNCF_E_NOMEM in the lazy neighbour build
+            raise PoisonedEngine.Boom("out of memory in the neighbour build")
+        return super().mae_device(predictor, users, items, ratings)
 
-def _poisoned_worker(rank, world, port, out):
+
+def _poisoned_worker(rank, world, port, out, where="fit"):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -104,9 +115,12 @@ def _poisoned_worker(rank, world, port, out):
     sharded = importlib.import_module(PKG + ".sharded")
     d = synth.syn_scaled(60, 60, 1500, seed=3, half_stars=True)
     tr = tuple(torch.from_numpy(a) for a in (d.train.users, d.train.items, d.train.ratings))
-    model = sharded.ShardedKnn(PoisonedEngine(O, rank, world, 5, bad_rank=1), dist, rank, world)
+    model = sharded.ShardedKnn(PoisonedEngine(O, rank, world, 5, bad_rank=1, where=where), dist, rank, world)
     try:
         model.fit(*tr)
+        if where == "mae":
+            te = tuple(torch.from_numpy(a) for a in (d.test.users, d.test.items, d.test.ratings))
+            model.mae(5, *te)
         out.put((rank, "no error", 0))
     except PoisonedEngine.Boom as e:
         out.put((rank, "own", e.status))
@@ -116,14 +130,16 @@ def _poisoned_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_fit_failure_on_one_rank_raises_on_every_rank():
+@pytest.mark.parametrize("where", ["fit", "mae"])
+def test_failure_on_one_rank_raises_on_every_rank(where):
+    """a rank whose fit — or whose lazy neighbour build inside mae — fails: every rank raises, none blocks in a collective"""
     import torch.multiprocessing as mp
 
     world = 3
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_poisoned_worker, args=(r, world, port, out)) for r in range(world)]
+    procs = [ctx.Process(target=_poisoned_worker, args=(r, world, port, out, where)) for r in range(world)]
     for p in procs:
         p.start()
     results = dict((r, (kind, st)) for r, kind, st in (out.get(timeout=120) for _ in range(world)))
