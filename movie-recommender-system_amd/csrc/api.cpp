@@ -139,7 +139,12 @@ int guarded(knncf_handle* h, F&& f) {
     } guard;
     try {
         int cur = -1;
-        if (hipGetDevice(&cur) == hipSuccess && cur != h->cfg.device) {
+        if (hipGetDevice(&cur) != hipSuccess) {
+            // (a thread without a usable HIP context, e.g. after a sticky error: nothing to restore, and the failure — if it
+            // persists — becomes this call's status instead of the call running on whatever device is current)
+            (void)hipGetLastError();
+            KN_HIP(hipSetDevice(h->cfg.device));
+        } else if (cur != h->cfg.device) {
             guard.prev = cur;
             KN_HIP(hipSetDevice(h->cfg.device));
         }
@@ -272,6 +277,10 @@ int32_t choose_head(knncf_handle* h, int32_t rows_total, bool symmetric) {
             if (cost < best) { best = cost; H = hc; }
             if (hc == I) break;
         }
+        // Jaccard handles count common items in the panel: fp16 holds the counts exactly up to 2048 (build_neighbors refuses a
+        // wider head unless KNNCF_FLAG_F32_PANEL lifts the limit) — the cost model must not pick what the build then refuses;
+        // the tail takes the remaining items and the counts stay exact
+        if (tr.jaccard && (h->cfg.flags & KNNCF_FLAG_F32_PANEL) == 0) H = std::min(H, 2048);
     }
     h->tail_pairs_full = tail_sq[H];
     return H;
@@ -435,6 +444,49 @@ void build_neighbors(knncf_handle* h, int32_t count) {
     hipStream_t sc = h->stream;   // consumer: select, exact re-rank
     KN_HIP(hipEventRecord(h->ev_ready, sc));  // everything queued so far (fit, B panel) precedes the producer
     KN_HIP(hipStreamWaitEvent(sp, h->ev_ready, 0));
+    // host copy of the build list (dense users in build order), fetched on first need
+    std::vector<int32_t> h_rows;
+    auto need_h_rows = [&] {
+        if (!h_rows.empty()) return;
+        h_rows.resize(count);
+        KN_HIP(hipMemcpyAsync(h_rows.data(), h->build_list.p, (size_t)count * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        KN_HIP(hipStreamSynchronize(st));
+    };
+    // rows (positions in the build list) whose anticipated thresholds overshot: once more through select + re-rank with the
+    // plain thresholds, out of the panel Sp (whole matrix: indexed by user; a row block based at position rb: by block row)
+    auto redo_marked = [&](const std::vector<int32_t>& marked, const void* Sp, bool by_user, int64_t rb) {
+        need_h_rows();
+        std::vector<int32_t> users(marked.size()), srow(marked.size());
+        for (size_t j = 0; j < marked.size(); ++j) {
+            users[j] = h_rows[marked[j]];
+            srow[j] = (int32_t)(marked[j] - rb);
+        }
+        TailEntries te{h->te_cnt.p, h->te_item.p, h->te_x.p, h->row_tail_abs.p, h->row_head_sq.p, h->row_len.p};
+        const int64_t chunk = std::min<int64_t>((int64_t)marked.size(), R);
+        h->redo_rows.ensure(2 * (size_t)chunk);
+        for (size_t j0 = 0; j0 < marked.size(); j0 += (size_t)R) {  // (the shortlist / group stores hold R rows)
+            const int32_t m = (int32_t)std::min<size_t>((size_t)R, marked.size() - j0);
+            KN_HIP(hipMemcpyAsync(h->redo_rows.p, users.data() + j0, (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            KN_HIP(hipMemcpyAsync(h->redo_rows.p + chunk, srow.data() + j0, (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            {
+                Stage s(h, &h->tm.select_ms);
+                launch_tail_select(tr, h->colmap.p, te, head < tr.I, Sp, by_user, s_fp16, U_pad, m, h->redo_rows.p, nt.k, eps_opnd, eps_rest, cap,
+                                   h->sel.cand_idx.p, h->sel.cand_approx.p, h->sel.cand_cnt.p, h->sel.cand_eps.p, h->sel.grp_v0.p, h->sel.grp_x.p,
+                                   select_gcap(nt.k), st, /*anticipate=*/false, by_user ? nullptr : h->redo_rows.p + chunk);
+                h->tm.select_launches += 1;
+            }
+            {
+                Stage s(h, &h->tm.rerank_ms);
+                launch_rerank(tr, nt, m, h->redo_rows.p, cap, h->sel.cand_idx.p, h->sel.cand_approx.p, h->sel.cand_cnt.p, h->sel.cand_eps.p,
+                              h->sel.stats.p, h->sel.row_entries.p, verify, st);
+            }
+            std::vector<int32_t> again(m);
+            KN_HIP(hipMemcpyAsync(again.data(), h->sel.cand_cnt.p, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            KN_HIP(hipStreamSynchronize(st));
+            for (int32_t j = 0; j < m; ++j) h->pinned_cnt[marked[j0 + j]] = again[j];
+        }
+    };
+    const bool per_block_redo = !use_sym && n_blocks > 1;
     for (int64_t b = 0; b < n_blocks; ++b) {
         const int64_t rb = b * R;
         const int32_t rows = (int32_t)std::min<int64_t>(R, count - rb);
@@ -468,7 +520,7 @@ void build_neighbors(knncf_handle* h, int32_t count) {
             h->tm.tail_pair_updates += h->tail_pairs_full * ((double)rows / (double)tr.U);
             h->tm.select_row_bytes += (double)s_elem * (double)rows * (double)tr.U;
         }
-        if (overlap) KN_HIP(hipEventRecord(h->ev_consumed[slot], sc));
+        if (overlap && !per_block_redo) KN_HIP(hipEventRecord(h->ev_consumed[slot], sc));
         {
             Stage s(h, &h->tm.rerank_ms, sc);
             launch_rerank(tr, nt, rows, d_rows, cap, h->sel.cand_idx.p, h->sel.cand_approx.p, h->sel.cand_cnt.p, h->sel.cand_eps.p,
@@ -476,58 +528,40 @@ void build_neighbors(knncf_handle* h, int32_t count) {
         }
         if (!overlap) KN_HIP(hipEventRecord(h->ev_consumed[slot], sc));
         KN_HIP(hipMemcpyAsync(h->pinned_cnt + rb, h->sel.cand_cnt.p, rows * sizeof(int32_t), hipMemcpyDeviceToHost, sc));
+        if (per_block_redo) {
+            // several row blocks (syn-1M, capped workspaces): the block's panel slot is about to be recycled, so rows whose
+            // anticipated thresholds overshot are re-selected NOW if they are many (one host round trip per block: the
+            // blocks of such builds take tens of milliseconds each)
+            KN_HIP(hipStreamSynchronize(sc));
+            std::vector<int32_t> marked;
+            for (int64_t r = rb; r < rb + rows; ++r)
+                if (h->pinned_cnt[r] > cap) marked.push_back((int32_t)r);
+            if ((int64_t)marked.size() > std::max<int64_t>(64, rows / 200)) {
+                redo_marked(marked, h->S[slot].p, false, rb);
+            }
+            if (overlap) KN_HIP(hipEventRecord(h->ev_consumed[slot], sc));  // (only now may the producer recycle S[slot])
+        }
     }
     KN_HIP(hipStreamSynchronize(sc));
     KN_HIP(hipStreamSynchronize(sp));
     // select.hip anticipates its emission thresholds and marks a row whose guess overshot (like one whose stores overflowed)
     // for the exact fallback below — a 7-sigma event per row when the dense user order is a pseudo-random column sample,
     // which HashSet ranks of the raw ids are.  Should a data set defeat that (many rows marked), the marked rows are not sent
-    // through the per-row exact path (milliseconds each) but once more through select + re-rank with the plain thresholds:
-    // the anticipation can then cost at most one extra pass.  (Whole-matrix builds: the similarity panel is still there.)
-    std::vector<int32_t> h_rows;
-    if (use_sym) {
+    // through the per-row exact path (milliseconds each, a U-sized sort each) but once more through select + re-rank with the
+    // plain thresholds (redo_marked): the anticipation can then cost at most one extra pass.  Whole-matrix builds and
+    // one-block row-block builds do it here (the similarity panel is still there); builds of several row blocks did it per
+    // block, before the block's panel slot was recycled (above).
+    if (use_sym || n_blocks == 1) {
         std::vector<int32_t> marked;
         for (int64_t r = 0; r < count; ++r)
             if (h->pinned_cnt[r] > cap) marked.push_back((int32_t)r);
-        if ((int64_t)marked.size() > std::max<int64_t>(64, count / 200)) {
-            h_rows.resize(count);
-            KN_HIP(hipMemcpyAsync(h_rows.data(), h->build_list.p, (size_t)count * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-            KN_HIP(hipStreamSynchronize(st));
-            std::vector<int32_t> users(marked.size());
-            for (size_t j = 0; j < marked.size(); ++j) users[j] = h_rows[marked[j]];
-            TailEntries te{h->te_cnt.p, h->te_item.p, h->te_x.p, h->row_tail_abs.p, h->row_head_sq.p, h->row_len.p};
-            h->redo_rows.ensure(std::min<int64_t>((int64_t)marked.size(), R));
-            for (size_t j0 = 0; j0 < marked.size(); j0 += (size_t)R) {  // (the shortlist / group stores hold R rows)
-                const int32_t m = (int32_t)std::min<size_t>((size_t)R, marked.size() - j0);
-                KN_HIP(hipMemcpyAsync(h->redo_rows.p, users.data() + j0, (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, st));
-                {
-                    Stage s(h, &h->tm.select_ms);
-                    launch_tail_select(tr, h->colmap.p, te, head < tr.I, h->S_full.p, true, s_fp16, U_pad, m, h->redo_rows.p, nt.k, eps_opnd, eps_rest, cap,
-                                       h->sel.cand_idx.p, h->sel.cand_approx.p, h->sel.cand_cnt.p, h->sel.cand_eps.p, h->sel.grp_v0.p, h->sel.grp_x.p,
-                                       select_gcap(nt.k), st, /*anticipate=*/false);
-                    h->tm.select_launches += 1;
-                }
-                {
-                    Stage s(h, &h->tm.rerank_ms);
-                    launch_rerank(tr, nt, m, h->redo_rows.p, cap, h->sel.cand_idx.p, h->sel.cand_approx.p, h->sel.cand_cnt.p, h->sel.cand_eps.p,
-                                  h->sel.stats.p, h->sel.row_entries.p, verify, st);
-                }
-                std::vector<int32_t> again(m);
-                KN_HIP(hipMemcpyAsync(again.data(), h->sel.cand_cnt.p, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-                KN_HIP(hipStreamSynchronize(st));
-                for (int32_t j = 0; j < m; ++j) h->pinned_cnt[marked[j0 + j]] = again[j];
-            }
-        }
+        if ((int64_t)marked.size() > std::max<int64_t>(64, count / 200)) redo_marked(marked, use_sym ? (const void*)h->S_full.p : (const void*)h->S[0].p, use_sym, 0);
     }
     // rows whose shortlist overflowed: exact row + stable descending sort (rare)
     for (int64_t r = 0; r < count; ++r) {
         h->tm.shortlist_total += std::min(h->pinned_cnt[r], cap);
         if (h->pinned_cnt[r] > cap) {
-            if (h_rows.empty()) {
-                h_rows.resize(count);
-                KN_HIP(hipMemcpyAsync(h_rows.data(), h->build_list.p, (size_t)count * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-                KN_HIP(hipStreamSynchronize(st));
-            }
+            need_h_rows();
             Stage s(h, &h->tm.rerank_ms);
             int32_t u = h_rows[r];
             h->sel.row_exact.ensure(tr.U);

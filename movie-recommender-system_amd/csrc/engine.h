@@ -17,7 +17,8 @@ inline int32_t select_gcap(int32_t k) { return 8192 * (int32_t)((k + 511) / 512 
 #ifndef KNNCF_TCOLS
 #define KNNCF_TCOLS 16384  // (A/B switch: 8192 = half-size tiles, three workgroups of k_tail_select per CU)
 #endif
-static constexpr int SELECT_TCOLS = KNNCF_TCOLS;  // <= 2^15: it_pack keeps the LDS cell of the column inside its tile in 15 bits
+static constexpr int SELECT_TCOLS = KNNCF_TCOLS;  // <= 2^14: it_pack keeps the BYTE address of the column's LDS cell inside its tile in 16 bits
+static_assert(SELECT_TCOLS <= 16384 && (SELECT_TCOLS & (SELECT_TCOLS - 1)) == 0, "it_pack: 16-bit cell byte address");
 
 // ---- sort_util.hip (stable LSD radix sort / sorted-unique, hand-written; K0 plumbing) ----
 struct SortWorkspace {
@@ -67,7 +68,7 @@ struct Train {
     bool item_stats_ready = false;
     // item-major copies for the sparse tail of the hybrid similarity (fp32 is enough: it only filters)
     DArr<int32_t> it_user;   // [n] dense user of the q-th entry in (item, user ascending) order
-    DArr<uint32_t> it_pack;  // [n] LDS cell of (user mod SELECT_TCOLS) << 17 | Q0.16 preprocessed rating: the sparse tail's 4-byte entry
+    DArr<uint32_t> it_pack;  // [n] the sparse tail's 4-byte entry: value field (16 bits, high) | byte address of the LDS cell of (user mod SELECT_TCOLS) — prep.hip: k_item_major
     DArr<double> it_dev;     // [n] normalized deviation of that entry (prediction gathers)
     DArr<uint32_t> it_t;     // [n] training file row of that entry (order of ratedI(i) :508-517)
     // per-item rater bitmaps over the dense user index + per-word exclusive rank prefixes: "did user x rate
@@ -200,7 +201,8 @@ void launch_tail_entries(const Train& tr, const int32_t* d_colmap, int32_t* te_c
 void launch_tail_select(const Train& tr, const int32_t* d_colmap, const TailEntries& te, bool has_tail, const void* S, bool s_by_user, bool s_fp16, int64_t lds,
                         int32_t n_rows, const int32_t* d_row_user, int32_t k, float eps_opnd, float eps_rest, int32_t cap,
                         int32_t* cand_idx, float* cand_approx, int32_t* cand_cnt, float* cand_eps, int32_t* grp_v0, float* grp_x,
-                        int32_t gcap, hipStream_t st, bool anticipate = true);
+                        int32_t gcap, hipStream_t st, bool anticipate = true, const int32_t* d_row_srow = nullptr);
+// (d_row_srow: row-block panels — the panel row of launch row r when it is not r itself: the re-select of a subset of a block)
 // (anticipate = false: the emission thresholds are the plain k-th largest value seen so far — api.cpp re-runs the rows of a
 // build whose anticipated thresholds overshot too often that way)
 // exact fp64 similarities of the shortlists in reference order, stable top-k

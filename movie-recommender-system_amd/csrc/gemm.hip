@@ -14,9 +14,11 @@
 // SOURCE address (16-B chunk c of row r sits in slot c ^ ((r >> 1) & 7), conflict-free for
 // ds_read_b128: the 16 lanes of a read group hit 16 distinct slots of the 256-B bank row).
 // Tile t+1 stays in flight across the barrier behind a counted vmcnt.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "engine.h"
@@ -353,6 +355,442 @@ k_gemm_nt_bf16(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, OT* _
     }
 }
 
+// a pointer whose value is the same in every lane, moved to scalar registers (buffer descriptors must be uniform)
+template <class T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<T*>(((uint64_t)hi << 32) | lo);
+}
+
+// stage_tile with the addressing off the vector registers: the tile origin is a uniform 64-bit pointer (scalar registers),
+// the lane part of the source offset is ONE kernel-invariant 32-bit register per operand — voff = (lane >> 3) * ld * 2 +
+// (((lane & 7) ^ (lane >> 4)) * 16): row and swizzled chunk of an EVEN 8-row piece; an odd piece's chunk differs in bit 2
+// ((row >> 1) & 7 gains 4), i.e. voff ^ 64 (ld * 2 is a multiple of 128) — and the piece's row block goes into the
+// scalar base.
+template <int ROWS, int WAVES>
+__device__ __forceinline__ void stage_tile_u(const bf16_t* g_uniform, uint32_t ld2, char* lds_tile, int wave, uint32_t voff) {
+    constexpr int LOADS = ROWS / 8 / WAVES;
+    static_assert(LOADS % 2 == 0, "pieces alternate between even and odd");
+    const char* base = reinterpret_cast<const char*>(uniform_ptr(g_uniform));
+#ifdef KNNCF_OV_ABL_NOLOAD  /* timing-only ablation (results are wrong): no operand loads */
+    return;
+#endif
+#pragma unroll
+    for (int j = 0; j < LOADS; ++j) {
+        const int piece = wave * LOADS + j;  // (wave * LOADS is even: parity of the piece == parity of j)
+        const char* src = base + (uint64_t)((uint32_t)piece * 8u * ld2) + (uint64_t)((j & 1) ? (voff ^ 64u) : voff);
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const bf16_t*>(src), (__attribute__((address_space(3))) void*)(lds_tile + piece * 1024), 16, 0, 0);
+    }
+}
+
+#ifdef KNNCF_OV_ABL_NOSTORE  /* timing-only ablation (results are wrong): the overlapped GEMM without its global stores */
+#define KN_OV_STORE "s_nop 0 ; "
+#define KN_OV_STORES 0
+#else
+#define KN_OV_STORE
+#define KN_OV_STORES 4
+#endif
+#ifndef KN_OV_POLICY
+#define KN_OV_POLICY "nt"  // (A/B switch: -DKN_OV_POLICY='""' plain, '"sc1"' write-through)
+#endif
+// ---- the overlapped form (fp16 panel, 256 x 256 tiles) ---------------------------------------------------------------
+// k_gemm_nt_bf16 above ADDS a tile's stores to its MFMA work: every store of the epilogue is queued in front of the next
+// tile's operand loads, and on gfx9 vmcnt counts loads and stores together and retires them in order, so the counted wait
+// for the second k-tile of the next tile also waits for every store of this one.  At K = 384 that is ~5 us of MFMA steps
+// plus ~10 us of stores (256 KB per off-diagonal tile at the CU's share of the HBM write rate) per tile.
+//
+// Here the finished tile does not leave through a workgroup-wide epilogue at all.  Its accumulators are converted to
+// fp16 in place (128 -> 64 registers per lane: two waves per SIMD hold 256 registers each, so the next tile's 128
+// accumulators fit beside them) and the wave drains them, EIGHT units to a tile, while it computes the next one: two
+// units per k-step, each through the wave's PRIVATE 4 KiB of LDS (no workgroup barrier: a wave's LDS operations execute in
+// order) —
+//   unit 2 i     : the wave's 32 x 64 block i as it is: 8 ds_write_b64 (a lane holds one row and runs of 4 columns), read
+//                  back as 16-byte pieces, 4 global stores of 8 rows x 128 contiguous bytes;
+//   unit 2 i + 1 : the same block MIRRORED (symmetric launches, off-diagonal tiles): 32 ds_write_b16 into the 64 x 32
+//                  transposed image, 4 global stores of 16 rows x 64 contiguous bytes, into tile (tn, tm).
+// The stores are spread evenly over the k-steps and the counted waits allow the stores of the previous k-step to stay
+// in flight (vmcnt(loads of the next stage + stores issued since)): the launch takes max(MFMA, stores) per tile instead
+// of their sum.  LDS: the 128 KiB operand ring + 8 x 4 KiB = all 160 KiB.  The stored values are bit for bit those of
+// k_gemm_nt_bf16 (same MFMA order, same clamp, same round-to-nearest-even conversion).
+template <bool F16, bool SYM, bool SPREAD>
+__global__ void __launch_bounds__(512)
+k_gemm_nt_ov(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, _Float16* __restrict__ C, int tiles_m, int tiles_n,
+             int k_tiles, int64_t lda, int64_t ldb, int64_t ldc, const uint32_t* __restrict__ tile_list, int n_listed, float clamp_hi) {
+    constexpr int WM = 4, WN = 2, WAVES_N = 4, WAVES = 8, TB = 256;
+    constexpr int TILE_BYTES = TileGeom<TB>::TILE_BYTES, STAGE_BYTES = TileGeom<TB>::STAGE_BYTES;
+    constexpr int LOADS_PER_STAGE = 2 * (TB / 8 / WAVES);  // 8 LDS-DMA instructions per wave per stage
+    static_assert(LOADS_PER_STAGE == 8, "the counted waits below assume 8 LDS-DMA instructions per wave per stage");
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    char* const ring = lds;
+
+    const int nwg = SYM ? n_listed : tiles_m * tiles_n;
+    const int xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
+    const int xcd_first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int xcd_end = xcd_first + (xcd < r ? q + 1 : q);
+    const int stride = ((int)gridDim.x - xcd + 7) >> 3;
+    int t = xcd_first + ((int)blockIdx.x >> 3);
+    if (t >= xcd_end) return;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wr = wave / WAVES_N, wc = wave % WAVES_N;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    char* const stg = lds + 2 * STAGE_BYTES + wave * 4096;  // this wave's private staging image
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    const uint32_t lda2 = (uint32_t)lda * 2u, ldb2 = (uint32_t)ldb * 2u;
+    const uint32_t sw16 = (uint32_t)(((lane & 7) ^ (lane >> 4)) * 16);
+    uint32_t voff_a = (uint32_t)(lane >> 3) * lda2 + sw16, voff_b = (uint32_t)(lane >> 3) * ldb2 + sw16;
+    // (opaque to the optimizer: it otherwise folds the lane part back into the tile origin — (tile row + lane row) * ld as a
+    // 64-bit product per lane and piece — and keeps twelve 64-bit addresses per tile in vector registers)
+    asm volatile("" : "+v"(voff_a), "+v"(voff_b));
+
+    auto tile_of = [&](int wg, int& tm, int& tn) {
+        if (SYM) {
+            const uint32_t packed = tile_list[wg];
+            tm = (int)(packed & 0xffffu);
+            tn = (int)(packed >> 16);
+            return;
+        }
+        const int GROUP = 8;
+        const int group_sz = GROUP * tiles_n;
+        const int gid = wg / group_sz;
+        const int first_m = gid * GROUP;
+        const int gm = min(GROUP, tiles_m - first_m);
+        tm = first_m + (wg % group_sz) % gm;
+        tn = (wg % group_sz) / gm;
+    };
+
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+    typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+    // the previous tile, converted: P[i][j][2 g + h] = columns 8 g + 4 fhalf + 2 h, + 1 of block (i, j), row frow
+    // the wave's row blocks 2 and 3 wait in P (32 registers) and leave under the next tile; blocks 0 and 1 leave at the tile's end
+    constexpr int NP = 2, UNITS = 4;
+    uint32_t P[NP][WN][8];
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int h = 0; h < 8; ++h) P[i][j][h] = 0u;
+    // Register plan (2 waves per SIMD: 256 registers each, one unified file on gfx950): the 128 accumulators of the running
+    // tile in the ACCUMULATION half, P + one fragment set + the addressing in the 128 architectural registers.  hipcc puts
+    // MFMA results into accumulation registers only when the kernel is known to use them; this (empty) statement says so.
+    int ptm = 0, ptn = 0;
+    int unit = 1000;  // next unit of the previous tile to drain (>= UNITS: none left)
+
+    // one unit of the previous tile through the wave's private image; returns the number of global stores it issued.
+    // The addressing is kept off the vector registers (P + one fragment set + addresses share 128): the global stores go
+    // through a buffer descriptor rooted at the unit's first element (scalar registers), the lane part of the offset is one
+    // kernel-invariant register per orientation, the row step rides in the scalar offset; the LDS addresses are one
+    // invariant register per access pattern plus immediates (the LDS stores are written as asm for that reason).
+    const uint32_t ldc2 = (uint32_t)ldc * 2u;                                              // bytes per row of C
+    const uint32_t vo_n = (uint32_t)(lane >> 3) * ldc2 + (uint32_t)(lane & 7) * 16u;       // both orientations: 8 rows x 128 B per store
+    const uint32_t stg_a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)stg;  // LDS byte address (4 KiB aligned)
+    // normal image: [32 rows][128 B], 16-byte slot s of row r at slot s ^ (r & 7); a lane writes 8 bytes of row frow
+    const uint32_t aw_n = stg_a + ((uint32_t)frow * 128u | (uint32_t)fhalf * 8u | (uint32_t)(frow & 7) * 16u);  // ^ (slot * 16)
+    const uint32_t lr_n = (uint32_t)(lane >> 3) * 128u + (uint32_t)(((lane & 7) ^ (lane >> 3)) * 16);
+    // A unit is ONE asm statement: 16 data registers in, 17 temporaries, the addressing in kernel-invariant registers — the
+    // compiler's version kept 64-bit per-lane addresses and spilled (a scratch reload is a vector-memory operation: its
+    // wait drains every store in flight, the opposite of the point).  A wave's LDS operations execute in order, so the reads
+    // see the writes without a wait; every buffer store waits for its own read only (lgkmcnt counts down as the four reads
+    // return in order); s_nop 1: a store of more than 8 bytes needs a wait state before its data registers may be rewritten.
+    // Both orientations leave as 4 stores of 8 rows x 128 contiguous bytes (scripts/microbench/store_pattern.hip: 5.4 TB/s
+    // for that shape against 6.1 linear — and 3.1 for 64-byte pieces, which is why the mirror unit spans TWO row blocks):
+    //   normal(I)    : the wave's 32 x 64 block I as it is — image [32 rows][128 B], 16-byte slot s of row r at s ^ (r & 7);
+    //   mirror(p, J) : rows 64 p .. + 64 of its 32-column sub-block J, transposed — image [32 rows = columns][128 B = 64 rows].
+    const uint32_t lra_n = stg_a + lr_n, lra_t = stg_a + (uint32_t)lane * 16u;
+    const uint32_t aw_m = stg_a + (uint32_t)fhalf * 512u + (uint32_t)frow * 2u;
+    const uint32_t so_1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(8u * ldc2));
+    auto drain_normal = [&](const uint32_t (&R)[WN][8], int I) -> int {
+        u32x4 q0, q1, q2, q3;
+        uint32_t tmp_a;
+        _Float16* Cg = C + ((int64_t)ptm * TB + wr * (WM * 32) + I * 32) * ldc + (int64_t)ptn * TB + wc * (WN * 32);
+        const uint64_t cb = reinterpret_cast<uint64_t>(uniform_ptr(Cg));
+        const u32x4 rs = {(uint32_t)cb, (uint32_t)(cb >> 32) & 0xffffu, 0x7fffffffu, 0x00020000u};
+        asm volatile(
+                "v_xor_b32 %[t], 0, %[aw]\n\tds_write2_b32 %[t], %[r00], %[r01] offset1:1\n\t"
+                "v_xor_b32 %[t], 16, %[aw]\n\tds_write2_b32 %[t], %[r02], %[r03] offset1:1\n\t"
+                "v_xor_b32 %[t], 32, %[aw]\n\tds_write2_b32 %[t], %[r04], %[r05] offset1:1\n\t"
+                "v_xor_b32 %[t], 48, %[aw]\n\tds_write2_b32 %[t], %[r06], %[r07] offset1:1\n\t"
+                "v_xor_b32 %[t], 64, %[aw]\n\tds_write2_b32 %[t], %[r10], %[r11] offset1:1\n\t"
+                "v_xor_b32 %[t], 80, %[aw]\n\tds_write2_b32 %[t], %[r12], %[r13] offset1:1\n\t"
+                "v_xor_b32 %[t], 96, %[aw]\n\tds_write2_b32 %[t], %[r14], %[r15] offset1:1\n\t"
+                "v_xor_b32 %[t], 112, %[aw]\n\tds_write2_b32 %[t], %[r16], %[r17] offset1:1\n\t"
+                "ds_read_b128 %[q0], %[lr] offset:0\n\t"
+                "ds_read_b128 %[q1], %[lr] offset:1024\n\t"
+                "ds_read_b128 %[q2], %[lr] offset:2048\n\t"
+                "ds_read_b128 %[q3], %[lr] offset:3072\n\t"
+                "s_waitcnt lgkmcnt(3)\n\t" KN_OV_STORE "buffer_store_dwordx4 %[q0], %[vo], %[rs], %[so0] offen " KN_OV_POLICY "\n\t"
+                "s_waitcnt lgkmcnt(2)\n\t" KN_OV_STORE "buffer_store_dwordx4 %[q1], %[vo], %[rs], %[so1] offen " KN_OV_POLICY "\n\t"
+                "s_waitcnt lgkmcnt(1)\n\t" KN_OV_STORE "buffer_store_dwordx4 %[q2], %[vo], %[rs], %[so2] offen " KN_OV_POLICY "\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t" KN_OV_STORE "buffer_store_dwordx4 %[q3], %[vo], %[rs], %[so3] offen " KN_OV_POLICY "\n\t"
+                "s_nop 1"
+            : [t] "=&v"(tmp_a), [q0] "=&v"(q0), [q1] "=&v"(q1), [q2] "=&v"(q2), [q3] "=&v"(q3)
+            : [aw] "v"(aw_n), [lr] "v"(lra_n), [vo] "v"(vo_n), [rs] "s"(rs), [so0] "s"(0u), [so1] "s"(so_1), [so2] "s"(2u * so_1), [so3] "s"(3u * so_1),
+              [r00] "v"(R[0][0]), [r01] "v"(R[0][1]), [r02] "v"(R[0][2]), [r03] "v"(R[0][3]), [r04] "v"(R[0][4]), [r05] "v"(R[0][5]), [r06] "v"(R[0][6]), [r07] "v"(R[0][7]), [r10] "v"(R[1][0]), [r11] "v"(R[1][1]), [r12] "v"(R[1][2]), [r13] "v"(R[1][3]), [r14] "v"(R[1][4]), [r15] "v"(R[1][5]), [r16] "v"(R[1][6]), [r17] "v"(R[1][7])
+            : "memory");
+        return KN_OV_STORES;
+    };
+    auto drain_mirror = [&](const uint32_t (&Ra)[WN][8], const uint32_t (&Rb)[WN][8], int pr, auto J_) -> int {
+        constexpr int J = decltype(J_)::value;
+        if (!SYM || ptm == ptn) return 0;
+        u32x4 q0, q1, q2, q3;
+        _Float16* Ct = C + ((int64_t)ptn * TB + wc * (WN * 32) + J * 32) * ldc + (int64_t)ptm * TB + wr * (WM * 32) + pr * 64;
+        const uint64_t cb = reinterpret_cast<uint64_t>(uniform_ptr(Ct));
+        const u32x4 rs = {(uint32_t)cb, (uint32_t)(cb >> 32) & 0xffffu, 0x7fffffffu, 0x00020000u};
+        asm volatile(
+                "ds_write_b16 %[aw], %[r00] offset:0\n\tds_write_b16_d16_hi %[aw], %[r00] offset:128\n\t"
+                "ds_write_b16 %[aw], %[r01] offset:256\n\tds_write_b16_d16_hi %[aw], %[r01] offset:384\n\t"
+                "ds_write_b16 %[aw], %[r02] offset:1024\n\tds_write_b16_d16_hi %[aw], %[r02] offset:1152\n\t"
+                "ds_write_b16 %[aw], %[r03] offset:1280\n\tds_write_b16_d16_hi %[aw], %[r03] offset:1408\n\t"
+                "ds_write_b16 %[aw], %[r04] offset:2048\n\tds_write_b16_d16_hi %[aw], %[r04] offset:2176\n\t"
+                "ds_write_b16 %[aw], %[r05] offset:2304\n\tds_write_b16_d16_hi %[aw], %[r05] offset:2432\n\t"
+                "ds_write_b16 %[aw], %[r06] offset:3072\n\tds_write_b16_d16_hi %[aw], %[r06] offset:3200\n\t"
+                "ds_write_b16 %[aw], %[r07] offset:3328\n\tds_write_b16_d16_hi %[aw], %[r07] offset:3456\n\t"
+                "ds_write_b16 %[aw], %[r10] offset:64\n\tds_write_b16_d16_hi %[aw], %[r10] offset:192\n\t"
+                "ds_write_b16 %[aw], %[r11] offset:320\n\tds_write_b16_d16_hi %[aw], %[r11] offset:448\n\t"
+                "ds_write_b16 %[aw], %[r12] offset:1088\n\tds_write_b16_d16_hi %[aw], %[r12] offset:1216\n\t"
+                "ds_write_b16 %[aw], %[r13] offset:1344\n\tds_write_b16_d16_hi %[aw], %[r13] offset:1472\n\t"
+                "ds_write_b16 %[aw], %[r14] offset:2112\n\tds_write_b16_d16_hi %[aw], %[r14] offset:2240\n\t"
+                "ds_write_b16 %[aw], %[r15] offset:2368\n\tds_write_b16_d16_hi %[aw], %[r15] offset:2496\n\t"
+                "ds_write_b16 %[aw], %[r16] offset:3136\n\tds_write_b16_d16_hi %[aw], %[r16] offset:3264\n\t"
+                "ds_write_b16 %[aw], %[r17] offset:3392\n\tds_write_b16_d16_hi %[aw], %[r17] offset:3520\n\t"
+                "ds_read_b128 %[q0], %[lr] offset:0\n\t"
+                "ds_read_b128 %[q1], %[lr] offset:1024\n\t"
+                "ds_read_b128 %[q2], %[lr] offset:2048\n\t"
+                "ds_read_b128 %[q3], %[lr] offset:3072\n\t"
+                "s_waitcnt lgkmcnt(3)\n\t" KN_OV_STORE "buffer_store_dwordx4 %[q0], %[vo], %[rs], %[so0] offen " KN_OV_POLICY "\n\t"
+                "s_waitcnt lgkmcnt(2)\n\t" KN_OV_STORE "buffer_store_dwordx4 %[q1], %[vo], %[rs], %[so1] offen " KN_OV_POLICY "\n\t"
+                "s_waitcnt lgkmcnt(1)\n\t" KN_OV_STORE "buffer_store_dwordx4 %[q2], %[vo], %[rs], %[so2] offen " KN_OV_POLICY "\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t" KN_OV_STORE "buffer_store_dwordx4 %[q3], %[vo], %[rs], %[so3] offen " KN_OV_POLICY "\n\t"
+                "s_nop 1"
+            : [q0] "=&v"(q0), [q1] "=&v"(q1), [q2] "=&v"(q2), [q3] "=&v"(q3)
+            : [aw] "v"(aw_m), [lr] "v"(lra_t), [vo] "v"(vo_n), [rs] "s"(rs), [so0] "s"(0u), [so1] "s"(so_1), [so2] "s"(2u * so_1), [so3] "s"(3u * so_1),
+              [r00] "v"(Ra[J][0]), [r01] "v"(Ra[J][1]), [r02] "v"(Ra[J][2]), [r03] "v"(Ra[J][3]), [r04] "v"(Ra[J][4]), [r05] "v"(Ra[J][5]), [r06] "v"(Ra[J][6]), [r07] "v"(Ra[J][7]), [r10] "v"(Rb[J][0]), [r11] "v"(Rb[J][1]), [r12] "v"(Rb[J][2]), [r13] "v"(Rb[J][3]), [r14] "v"(Rb[J][4]), [r15] "v"(Rb[J][5]), [r16] "v"(Rb[J][6]), [r17] "v"(Rb[J][7])
+            : "memory");
+        return KN_OV_STORES;
+    };
+    // the four units of the row blocks kept in P (blocks 2 and 3 = row pair 1): two per k-step
+    auto drain_unit = [&](int u) -> int {
+        switch (u) {
+            case 0: return drain_normal(P[0], 2);
+            case 1: return drain_normal(P[1], 3);
+            case 2: return drain_mirror(P[0], P[1], 1, std::integral_constant<int, 0>{});
+            default: return drain_mirror(P[0], P[1], 1, std::integral_constant<int, 1>{});
+        }
+    };
+
+#ifdef KNNCF_OV_ABL_HOTLOAD  /* timing-only ablation (results are wrong): every tile's operands are the panel's first rows (L2-hot) */
+#define KN_OV_ROW(x) 0
+#else
+#define KN_OV_ROW(x) (x)
+#endif
+    int tm, tn;
+    tile_of(t, tm, tn);
+    const bf16_t* Ag = A + (int64_t)KN_OV_ROW(tm) * TB * lda;
+    const bf16_t* Bg = B + (int64_t)KN_OV_ROW(tn) * TB * ldb;
+    stage_tile_u<TB, WAVES>(Ag, lda2, ring, uwave, voff_a);
+    stage_tile_u<TB, WAVES>(Bg, ldb2, ring + TILE_BYTES, uwave, voff_b);
+    int slot = 0;
+    // Counted waits by bookkeeping instead of by position: `ops` counts every vector-memory operation this wave has issued
+    // (8 LDS-DMAs per operand stage, 4 stores per unit), mark[s] is its value right after the stage into slot s was issued —
+    // so when k-tile `slot` is needed, exactly ops - mark[slot] younger operations may still be in flight (vmcnt retires
+    // in order: loads, LDS-DMAs and stores together).  A smaller immediate only waits longer; the immediates are multiples
+    // of 4 up to 32.
+    uint32_t ops = LOADS_PER_STAGE, mark[2] = {LOADS_PER_STAGE, 0u};
+    auto wait_for = [&](int s) {
+        const uint32_t allow = ops - mark[s];
+        if (allow >= 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else if (allow >= 28) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+        else if (allow >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else if (allow >= 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        else if (allow >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (allow >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (allow >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (allow >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    bool pre_issued = false;  // the second k-tile of this tile was requested at the end of the previous one
+    // Where the four deferred units go: with six or more k-steps one per k-step from the third on — the 16 stores of the
+    // tile's end then have two k-steps of their own to drain — otherwise two per k-step from the first.
+    constexpr bool spread = SPREAD;  // (the launcher: k_tiles >= 6)
+
+    for (;;) {
+        const int t_next = t + stride;
+        const bool more = t_next < xcd_end;
+        int tm2 = 0, tn2 = 0;
+        if (more) tile_of(t_next, tm2, tn2);
+        const bf16_t* Ag2 = A + (int64_t)KN_OV_ROW(tm2) * TB * lda;
+        const bf16_t* Bg2 = B + (int64_t)KN_OV_ROW(tn2) * TB * ldb;
+
+        f32x16 acc[WM][WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        for (int kt = 0; kt < k_tiles; ++kt) {
+            char* cur = ring + slot * STAGE_BYTES;
+            char* nxt = ring + (slot ^ 1) * STAGE_BYTES;
+            const bool in_tile = kt + 1 < k_tiles;
+            if (kt == 0 && pre_issued) {
+                pre_issued = false;  // (k-tile 1 is already on its way into `nxt`)
+            } else if (in_tile) {
+                stage_tile_u<TB, WAVES>(Ag + (int64_t)(kt + 1) * BK, lda2, nxt, uwave, voff_a);
+                stage_tile_u<TB, WAVES>(Bg + (int64_t)(kt + 1) * BK, ldb2, nxt + TILE_BYTES, uwave, voff_b);
+                ops += LOADS_PER_STAGE;
+                mark[slot ^ 1] = ops;
+            } else if (more) {
+                stage_tile_u<TB, WAVES>(Ag2, lda2, nxt, uwave, voff_a);
+                stage_tile_u<TB, WAVES>(Bg2, ldb2, nxt + TILE_BYTES, uwave, voff_b);
+                ops += LOADS_PER_STAGE;
+                mark[slot ^ 1] = ops;
+            }
+            wait_for(slot);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            // Fragments: one A fragment ahead of the MFMA pair that uses the current one, the B pair of the next k-substep
+            // behind the last A fragment of this one — 24 registers.
+            {
+                const char* ca = cur;
+                const char* cb = cur + TILE_BYTES;
+                const int arow = wr * (WM * 32) + frow, brow = wc * (WN * 32) + frow;
+                bf16x8 b0 = read_frag(cb, brow, fhalf), b1 = read_frag(cb, brow + 32, fhalf);
+                bf16x8 a_cur = read_frag(ca, arow, fhalf);
+                const bool unit_step = !spread || kt >= 2;
+#pragma unroll
+                for (int ks = 0; ks < BK / 16; ++ks) {
+                    bf16x8 b0n = b0, b1n = b1;
+#pragma unroll
+                    for (int i = 0; i < WM; ++i) {
+                        bf16x8 a_next = a_cur;
+                        if (i + 1 < WM) {
+                            a_next = read_frag(ca, arow + (i + 1) * 32, ks * 2 + fhalf);
+                        } else if (ks + 1 < BK / 16) {
+                            a_next = read_frag(ca, arow, (ks + 1) * 2 + fhalf);
+                            b0n = read_frag(cb, brow, (ks + 1) * 2 + fhalf);
+                            b1n = read_frag(cb, brow + 32, (ks + 1) * 2 + fhalf);
+                        }
+#ifndef KNNCF_OV_ABL_NOMFMA  /* timing-only ablation (results are wrong): no MFMA work */
+                        acc[i][0] = mfma<F16>(b0, a_cur, acc[i][0]);
+                        acc[i][1] = mfma<F16>(b1, a_cur, acc[i][1]);
+#else
+                        acc[i][0][0] += (float)a_cur[0] + (float)b0[0];
+                        acc[i][1][0] += (float)a_cur[1] + (float)b1[0];
+#endif
+                        a_cur = a_next;
+                    }
+                    b0 = b0n;
+                    b1 = b1n;
+                    // units of the previous tile, behind the first (and, when they come two to a k-step, the third) MFMA
+                    // group; the next k-substep's fragments are already requested
+                    if ((ks == 0 || (ks == 2 && !spread)) && unit_step && unit < UNITS) {
+                        ops += (uint32_t)drain_unit(unit);
+                        ++unit;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // everyone is done reading `cur` before it is restaged
+            asm volatile("" ::: "memory");
+            slot ^= 1;
+        }
+        // The slot just consumed is free: the next tile's SECOND k-tile is requested before this tile's end stores are
+        // queued, so that they stand behind it in the in-order count and the next tile's first two k-steps do not wait for them.
+        if (more && k_tiles >= 2) {
+            char* nxt = ring + (slot ^ 1) * STAGE_BYTES;
+            stage_tile_u<TB, WAVES>(Ag2 + BK, lda2, nxt, uwave, voff_a);
+            stage_tile_u<TB, WAVES>(Bg2 + BK, ldb2, nxt + TILE_BYTES, uwave, voff_b);
+            ops += LOADS_PER_STAGE;
+            mark[slot ^ 1] = ops;
+            pre_issued = true;
+        }
+        // short K (fewer k-steps than units): what is left of the previous tile leaves here, not overlapped
+        while (unit < UNITS) {
+            ops += (uint32_t)drain_unit(unit);
+            ++unit;
+        }
+        ptm = tm;
+        ptn = tn;
+        // this tile -> fp16 (clamp, round to nearest even: the values k_gemm_nt_bf16 stores).  Row blocks 0 and 1 leave right
+        // away (16 stores: they drain under the next tile's first two k-steps), blocks 2 and 3 wait in P
+        auto convert = [&](uint32_t (&R)[WN][8], auto I_) {
+            constexpr int I = decltype(I_)::value;
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    h2 v;
+                    v[0] = (_Float16)fminf(fmaxf(acc[I][j][2 * h], -clamp_hi), clamp_hi);
+                    v[1] = (_Float16)fminf(fmaxf(acc[I][j][2 * h + 1], -clamp_hi), clamp_hi);
+                    R[j][h] = __builtin_bit_cast(uint32_t, v);
+                }
+        };
+        {
+            uint32_t Q0[WN][8], Q1[WN][8];
+            convert(Q0, std::integral_constant<int, 0>{});
+            ops += (uint32_t)drain_normal(Q0, 0);
+            convert(Q1, std::integral_constant<int, 1>{});
+            ops += (uint32_t)drain_normal(Q1, 1);
+            ops += (uint32_t)drain_mirror(Q0, Q1, 0, std::integral_constant<int, 0>{});
+            ops += (uint32_t)drain_mirror(Q0, Q1, 0, std::integral_constant<int, 1>{});
+        }
+        convert(P[0], std::integral_constant<int, 2>{});
+        convert(P[1], std::integral_constant<int, 3>{});
+        unit = 0;
+        if (!more) break;
+        t = t_next;
+        tm = tm2;
+        tn = tn2;
+        Ag = Ag2;
+        Bg = Bg2;
+    }
+    while (unit < UNITS) {  // the last tile of this workgroup
+        (void)drain_unit(unit);
+        ++unit;
+    }
+}
+
+template <bool F16, bool SYM, bool SPREAD>
+static void launch_gemm_ov_t(const bf16_t* A, const bf16_t* B, _Float16* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                           int64_t ldc, const uint32_t* tile_list, int64_t n_listed, bool clamp, hipStream_t st) {
+    constexpr int TB = 256;
+    constexpr int SMEM = 2 * TileGeom<TB>::STAGE_BYTES + 8 * 4096;
+    static_assert(SMEM <= 160 * 1024, "gemm: LDS plan exceeds the CU's 160 KiB");
+    const int64_t tiles = SYM ? n_listed : (M / TB) * (N / TB);
+    KN_REQUIRE(tiles > 0 && tiles < (1ll << 31), KNNCF_E_INVALID, "gemm: grid too large");
+    static PerDeviceState state;
+    const int64_t slots = (int64_t)per_device_at_least(state, 1, [&](size_t) {
+        KN_HIP(hipFuncSetAttribute((const void*)k_gemm_nt_ov<F16, SYM, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        int dev = 0, cus = 0;
+        KN_HIP(hipGetDevice(&dev));
+        KN_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        return (size_t)std::max(1, cus);  // all of the CU's LDS: one workgroup per CU
+    });
+    const unsigned grid = (unsigned)(tiles < slots ? tiles : slots);
+    k_gemm_nt_ov<F16, SYM, SPREAD><<<grid, 512, SMEM, st>>>(A, B, C, (int)(M / TB), (int)(N / TB), (int)(K / BK), lda, ldb, ldc, tile_list,
+                                                    (int)n_listed, clamp ? 1.0f : 65504.0f);
+    KN_HIP(hipGetLastError());
+}
+
+template <bool F16, bool SYM>
+static void launch_gemm_ov(const bf16_t* A, const bf16_t* B, _Float16* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                           int64_t ldc, const uint32_t* tile_list, int64_t n_listed, bool clamp, hipStream_t st) {
+    static const bool no_spread = getenv("KNNCF_GEMM_NO_SPREAD") != nullptr;  // A/B switch for measurements
+    if (K / BK >= 6 && !no_spread) launch_gemm_ov_t<F16, SYM, true>(A, B, C, M, N, K, lda, ldb, ldc, tile_list, n_listed, clamp, st);
+    else launch_gemm_ov_t<F16, SYM, false>(A, B, C, M, N, K, lda, ldb, ldc, tile_list, n_listed, clamp, st);
+}
+
+// (A/B switch for measurements: KNNCF_GEMM_NO_OVERLAP=1 takes the epilogue-at-the-end kernel for fp16 panels too)
+static bool gemm_overlap_enabled() {
+    static const bool off = getenv("KNNCF_GEMM_NO_OVERLAP") != nullptr;
+    return !off;
+}
+
 template <bool F16, class OT, int WM, int WN, int WAVES_M, int WAVES_N, bool SYM>
 static void launch_gemm_cfg(const bf16_t* A, const bf16_t* B, OT* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                             int64_t ldb, int64_t ldc, const uint32_t* tile_list, int64_t n_listed, bool clamp, hipStream_t st) {
@@ -395,6 +833,12 @@ void launch_gemm_nt(const bf16_t* A, const bf16_t* B, void* C, bool c_fp16, int6
                     int64_t ldb, int64_t ldc, bool fp16, bool clamp, hipStream_t st) {
     KN_REQUIRE(M % 128 == 0 && N % 128 == 0 && K % BK == 0 && K > 0, KNNCF_E_INVALID, "gemm: shape not tile-aligned");
     KN_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, KNNCF_E_INVALID, "gemm: leading dimensions must be multiples of 8");
+    static const bool force_small = getenv("KNNCF_GEMM_TILE128") != nullptr;
+    if (c_fp16 && M % 256 == 0 && N % 256 == 0 && !force_small && gemm_overlap_enabled()) {
+        if (fp16) launch_gemm_ov<true, false>(A, B, static_cast<_Float16*>(C), M, N, K, lda, ldb, ldc, nullptr, 0, clamp, st);
+        else launch_gemm_ov<false, false>(A, B, static_cast<_Float16*>(C), M, N, K, lda, ldb, ldc, nullptr, 0, clamp, st);
+        return;
+    }
     if (fp16 && c_fp16) launch_gemm_t<true, _Float16>(A, B, static_cast<_Float16*>(C), M, N, K, lda, ldb, ldc, clamp, st);
     else if (fp16) launch_gemm_t<true, float>(A, B, static_cast<float*>(C), M, N, K, lda, ldb, ldc, clamp, st);
     else if (c_fp16) launch_gemm_t<false, _Float16>(A, B, static_cast<_Float16*>(C), M, N, K, lda, ldb, ldc, clamp, st);
@@ -421,6 +865,11 @@ void launch_gemm_sym(const bf16_t* B, void* C, bool c_fp16, int64_t N, int64_t K
         launch_gemm_cfg<true, _Float16, 2, 2, 2, 2, true>(B, B, static_cast<_Float16*>(C), N, N, K, ldb, ldb, ldc, d_tile_list, n_listed, clamp, st);
         return;
     }
+    if (c_fp16 && gemm_overlap_enabled()) {
+        if (fp16) launch_gemm_ov<true, true>(B, B, static_cast<_Float16*>(C), N, N, K, ldb, ldb, ldc, d_tile_list, n_listed, clamp, st);
+        else launch_gemm_ov<false, true>(B, B, static_cast<_Float16*>(C), N, N, K, ldb, ldb, ldc, d_tile_list, n_listed, clamp, st);
+        return;
+    }
     if (fp16 && c_fp16) launch_gemm_cfg<true, _Float16, 4, 2, 2, 4, true>(B, B, static_cast<_Float16*>(C), N, N, K, ldb, ldb, ldc, d_tile_list, n_listed, clamp, st);
     else if (fp16) launch_gemm_cfg<true, float, 4, 2, 2, 4, true>(B, B, static_cast<float*>(C), N, N, K, ldb, ldb, ldc, d_tile_list, n_listed, clamp, st);
     else if (c_fp16) launch_gemm_cfg<false, _Float16, 4, 2, 2, 4, true>(B, B, static_cast<_Float16*>(C), N, N, K, ldb, ldb, ldc, d_tile_list, n_listed, clamp, st);
@@ -428,3 +877,57 @@ void launch_gemm_sym(const bf16_t* B, void* C, bool c_fp16, int64_t N, int64_t K
 }
 
 }  // namespace knncf
+
+// ---- measurement hook (not part of include/knncf.h): the similarity GEMM alone on a synthetic panel ----------------------
+// scripts/microbench/gemm_bench.py: milliseconds per launch of the symmetric (sym = 1) or the row-block (sym = 0, M rows)
+// form at N users x K head columns, fp16 operands and panel; the operand panel is filled with a cheap pattern (values in
+// [-1/16, 1/16]: the MFMA rate does not depend on the data, the chip's clock under load does a little).
+__global__ void k_debug_fill(knncf::bf16_t* p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) reinterpret_cast<_Float16*>(p)[i] = (_Float16)((float)((int)((i * 2654435761u) >> 20 & 255) - 128) * (1.0f / 2048.0f));
+}
+
+extern "C" int knncf_debug_gemm_bench(int device, int64_t N, int64_t K, int64_t M, int sym, int iters, double* ms_per_launch) {
+    using namespace knncf;
+    try {
+        KN_HIP(hipSetDevice(device));
+        KN_REQUIRE(N % 256 == 0 && K % 64 == 0 && M % 256 == 0 && iters > 0 && ms_per_launch, KNNCF_E_INVALID, "bad shape");
+        DArr<bf16_t> B;
+        DArr<_Float16> C;
+        DArr<uint32_t> tiles;
+        B.alloc((size_t)N * K);
+        const int64_t rows = sym ? N : M;
+        C.alloc((size_t)rows * N);
+        k_debug_fill<<<(unsigned)ceil_div(N * K, 256), 256>>>(B.p, N * K);
+        std::vector<uint32_t> list;
+        int64_t n_listed = 0;
+        if (sym) {
+            gemm_sym_tile_list((int32_t)(N / 256), list, 8);
+            n_listed = (int64_t)list.size();
+            tiles.alloc(list.size());
+            KN_HIP(hipMemcpy(tiles.p, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
+        hipEvent_t a, b;
+        KN_HIP(hipEventCreate(&a));
+        KN_HIP(hipEventCreate(&b));
+        auto once = [&] {
+            if (sym) launch_gemm_sym(B.p, C.p, true, N, K, K, N, true, true, tiles.p, n_listed, nullptr, 256);
+            else launch_gemm_nt(B.p, B.p, C.p, true, M, N, K, K, K, N, true, true, nullptr);
+        };
+        once();
+        KN_HIP(hipDeviceSynchronize());
+        KN_HIP(hipEventRecord(a, nullptr));
+        for (int i = 0; i < iters; ++i) once();
+        KN_HIP(hipEventRecord(b, nullptr));
+        KN_HIP(hipEventSynchronize(b));
+        float ms = 0.f;
+        KN_HIP(hipEventElapsedTime(&ms, a, b));
+        *ms_per_launch = (double)ms / iters;
+        (void)hipEventDestroy(a);
+        (void)hipEventDestroy(b);
+        return KNNCF_OK;
+    } catch (const knncf::Error& e) {
+        fprintf(stderr, "knncf_debug_gemm_bench: %s\n", e.what());
+        return e.status;
+    }
+}

@@ -253,6 +253,14 @@ bool read_ratings_cache(const char* cache_path, int64_t src_size, int64_t src_mt
               h.src_mtime_ns == src_mtime_ns && h.sep_len == strlen(separator) && h.sep_len <= sizeof h.sep &&
               memcmp(h.sep, separator, h.sep_len) == 0;
     if (ok) {
+        // the header's row count is checked against the file's own length before anything is allocated: a corrupt or
+        // truncated cache with a huge n must not ask for terabytes (which overcommit grants lazily) — and n stays below the
+        // fit's own limit of 2^29 rows, so the byte counts below cannot wrap
+        struct stat cst;
+        ok = h.n < ((int64_t)1 << 29) && fstat(fileno(f), &cst) == 0 &&
+             (int64_t)cst.st_size == (int64_t)sizeof(CacheHeader) + h.n * 16;
+    }
+    if (ok) {
         const size_t cnt = h.n > 0 ? (size_t)h.n : 1;
         out->users = (int32_t*)malloc(cnt * sizeof(int32_t));
         out->items = (int32_t*)malloc(cnt * sizeof(int32_t));

@@ -1013,16 +1013,23 @@ __global__ void k_item_major(int64_t n, const uint32_t* __restrict__ perm_iu, co
     const double dev = __longlong_as_double((long long)(((unsigned long long)r0.w << 32) | r0.z));
     const int32_t user = (int32_t)r1.x;
     it_user[q] = user;
-    {  // tail word of select.hip: LDS cell of the column inside its tile (15 bits, high) | preprocessed rating as
-       // signed Q0.16 (17 bits, low).  The cell index already carries select.hip's accumulator layout (the low and the
-       // high 4 columns of every group of 8 live in separate halves: conflict-free 16-byte read-out), so the kernel
-       // spends no instruction on it.
-        int32_t qv = __double2int_rn(pre * 65536.0);
-        qv = min(max(qv, -65536), 65535);
-        if (ones) qv = 1;  // Jaccard handles count common items: every tail entry weighs 1 (select.hip reads the counts out unscaled)
+    {  // Tail word of select.hip: W = (value field, 16 bits, high) | (BYTE address of the column's LDS cell inside its tile, 16
+       // bits, low).  The kernel uses the WHOLE word as the rater-side factor (one v_cvt_f32_i32, no field extraction) and
+       // masks the address out with one v_and: W / TAIL_SCALE must therefore approximate pre as a whole, so the value field
+       // is rounded AFTER subtracting the address bits — |W - pre * TAIL_SCALE| <= 2^15, i.e. |W / TAIL_SCALE - pre| <=
+       // 2^-16 (1 + 2^-15): the Q0.16 budget of the row's error band (select.hip: tail_abs * 1.0001 / 65536).  TAIL_SCALE =
+       // 2^31 - 2^16 keeps the field inside int16 for |pre| <= 1 without clamping.  The cell address already carries
+       // select.hip's accumulator layout (the low and the high 4 columns of every group of 8 live in separate halves:
+       // conflict-free 16-byte read-out).
         const uint32_t c = (uint32_t)user & (uint32_t)(SELECT_TCOLS - 1);
         const uint32_t cell = (((c >> 3) << 2) | (c & 3u)) + ((c & 4u) ? (uint32_t)(SELECT_TCOLS / 2) : 0u);
-        it_pack[q] = (cell << 17) | ((uint32_t)qv & 0x1ffffu);
+        const uint32_t addr = cell << 2;  // < 2^16 (SELECT_TCOLS <= 16384)
+        // Jaccard handles count common items: every tail entry weighs 2^30 and the row-side factor is 2^-30 (select.hip rounds
+        // the product to the nearest integer: 1)
+        const double target = ones ? 1073741824.0 : fmin(fmax(pre, -1.0), 1.0) * 2147418112.0;
+        long long top = __double2ll_rn((target - (double)addr) / 65536.0);
+        top = top < -32768 ? -32768 : (top > 32767 ? 32767 : top);
+        it_pack[q] = ((uint32_t)(int32_t)top << 16) + addr;
     }
     it_dev[q] = dev;
     it_t[q] = r1.y;

@@ -57,7 +57,7 @@ static constexpr int NG = CPT / 8;
 static_assert(CPT <= 32, "the survivor mask of a thread is one 32-bit word");
 static constexpr int EMAX = 256;     // row positions whose tail entries (16 B each) are held in LDS at a time
 static constexpr int PMAX = 1024;    // pieces per (chunk, tile) with a direct piece -> entry table in LDS
-static constexpr int MAXT = TCOLS >= 16384 ? 16 : 24;  // tiles whose per-entry rater counts are packed into registers
+static constexpr int MAXT = TCOLS >= 16384 ? 12 : 24;  // tiles whose per-entry rater counts are packed into registers (12 x 16 384 columns: up to 196 608 users)
 static constexpr int WAVES_PER_EU = TCOLS >= 16384 ? 4 : 6;  // two / three 512-thread workgroups per CU (LDS: 79 / 47 KiB each)
 static constexpr int TAIL_G = 8;           // pieces per group of the drain (two groups in flight per wave)
 // the tail is accumulated in Q7.24 fixed point with integer LDS atomics (ds_add_u32; the float form
@@ -65,7 +65,11 @@ static constexpr int TAIL_G = 8;           // pieces per group of the drain (two
 // which the per-common-item term of row_eps covers.  The rater-side factor comes as Q0.16 (4-byte tail
 // entries: half the L2/MALL traffic of an (id, fp32) pair); its rounding, <= 2^-16 |pre(u,i)| per product,
 // is added to the row's error band exactly (tail_eps).
-static constexpr float TAIL_FIX = 256.0f;  // x * 2^8 * (y * 2^16) = x y 2^24
+// it_pack's word W ~ y * (2^31 - 2^16) (prep.hip: k_item_major); the row-side factor is x * 2^24 / (2^31 - 2^16), so that
+// W * factor = x y 2^24 (Q7.24); Jaccard handles: W ~ 2^30, factor 2^-30, product 1
+static constexpr double TAIL_SCALE = 2147418112.0;
+static constexpr float TAIL_FIX = (float)(16777216.0 / TAIL_SCALE);
+static constexpr float TAIL_FIX_JAC = 1.0f / 1073741824.0f;
 static constexpr float TAIL_UNFIX = 1.0f / 16777216.0f;
 
 // The histogram covers [HIST_LO, HIST_LO + 1) with NBINS bins of width 1/NBINS; values outside land in the end
@@ -77,10 +81,11 @@ __device__ __forceinline__ int sim_bin(float x) {
     return min(max(b, 0), NBINS - 1);
 }
 
-// rigorous bound on |S[u][v] - s_uv|: operand rounding (eps_base) plus fp32 accumulation — adding a
-// zero product is exact, so at most 2 roundings per common item, each <= 2^-24 of a partial sum <= 1.01
+// rigorous bound on |S[u][v] - s_uv|: operand rounding (eps_base) plus, per common item, the roundings of the tail product
+// (the rater-side word to fp32, the multiplication, the conversion to Q7.24) and of the dense part's fp32 accumulation —
+// adding a zero product is exact, so at most 3 roundings per common item, each <= 2^-24 of a quantity <= 1.01
 __device__ __forceinline__ float row_eps(float eps_base, int64_t row_len) {
-    return eps_base + (float)row_len * 2.0f * 6.1e-8f;
+    return eps_base + (float)row_len * 3.0f * 6.1e-8f;
 }
 
 struct TailArgs {
@@ -99,7 +104,7 @@ struct TailArgs {
     // chain s_col -> colmap -> LDS slot atomic; and the two per-row sums of the error band
     const int32_t* te_cnt;   // [U] tail entries of the row
     const int32_t* te_item;  // [n] item of the j-th tail entry of row u at u_ptr[u] + j
-    const float* te_x;       // [n] pre(u, item) * 2^8
+    const float* te_x;       // [n] pre(u, item) * TAIL_FIX
     const float* row_tail_abs;  // [U] sum over the row's tail entries of |pre(u, i)|
     const float* row_head_sq;   // [U] sum over the row's head entries of pre(u, i)^2
     const float* row_len;       // Jaccard handles: [U rounded up to a tile + a tile] |I(v)| as float (1.0 in the padding)
@@ -133,7 +138,7 @@ __global__ void k_tail_entries(int32_t u_lo, int32_t U, const int64_t* __restric
         if (is_tail) {
             const int32_t slot = n_out + __popcll(m & ((1ull << lane) - 1ull));
             te_item[ub + slot] = item;
-            te_x[ub + slot] = ones ? 1.0f : x * 256.0f;  // (ones: Jaccard handles count — factor 1 x entry value 1)
+            te_x[ub + slot] = ones ? TAIL_FIX_JAC : x * TAIL_FIX;  // (ones: Jaccard handles count — factor 2^-30 x entry value 2^30)
         }
         n_out += __popcll(m);
     }
@@ -253,7 +258,7 @@ struct Raw8<_Float16> {
 // the quotient is the correctly rounded fp32 image of the exact similarity and the error band is a few 1e-7.
 template <class ST, bool JAC>
 __global__ void __launch_bounds__(TPB, WAVES_PER_EU) k_tail_select(const ST* __restrict__ S, int32_t s_by_user, int64_t ld, int32_t n_rows,
-                                                     const int32_t* __restrict__ row_user, TailArgs T, int32_t U,
+                                                     const int32_t* __restrict__ row_user, const int32_t* __restrict__ row_srow, TailArgs T, int32_t U,
                                                      int32_t kk, float eps_opnd, float eps_rest, int32_t cap, int32_t* __restrict__ cand_idx,
                                                      float* __restrict__ cand_approx, int32_t* __restrict__ cand_cnt,
                                                      float* __restrict__ cand_eps, int32_t* __restrict__ grp_v0,
@@ -287,7 +292,9 @@ __global__ void __launch_bounds__(TPB, WAVES_PER_EU) k_tail_select(const ST* __r
     const int32_t u = row_user[r];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t ub = T.u_ptr[u], ue = T.u_ptr[u + 1];
-    const ST* row = S + (int64_t)(s_by_user ? u : r) * ld;  // (symmetric path: S is the whole matrix, indexed by dense user)
+    // (symmetric path: S is the whole matrix, indexed by dense user; row blocks: by block row — row_srow when the launch
+    // covers a subset of the block)
+    const ST* row = S + (int64_t)(s_by_user ? u : (row_srow ? row_srow[r] : r)) * ld;
     int32_t* out_idx = cand_idx + (int64_t)r * cap;
     float* out_apx = cand_approx + (int64_t)r * cap;
     // provisional store of the row: whole GROUPS of 8 columns (first column + the 8 values) whose maximum reached the
@@ -377,12 +384,17 @@ __global__ void __launch_bounds__(TPB, WAVES_PER_EU) k_tail_select(const ST* __r
         if ((int32_t)threadIdx.x < ne) {
             uint32_t qb, cnt;
             if (reg_counts) {
-                uint32_t ww = cw[0];
-#pragma unroll
-                for (int t2 = 1; t2 < MAXT / 2; ++t2) ww = ((tile >> 1) == t2) ? cw[t2] : ww;
-                cnt = (ww >> (16 * (tile & 1))) & 0xffffu;
+                // the counts are consumed in tile order: the current pair of tiles always sits in cw[0], and after every odd
+                // tile the words move down one place (static indices only: a select chain over the tile index was turned
+                // into a scratch array by the compiler — one dependent scratch load per tile whose vmcnt(0) also drained the
+                // panel loads in flight)
+                cnt = (cw[0] >> (16 * (tile & 1))) & 0xffffu;
                 qb = cur_b;
                 cur_b += cnt;
+                if (tile & 1) {
+#pragma unroll
+                    for (int t2 = 0; t2 + 1 < MAXT / 2; ++t2) cw[t2] = cw[t2 + 1];
+                }
             } else {
                 const uint32_t* tb = (n_chunks > 1 ? T.it_tile + (int64_t)e_item[threadIdx.x] * T.tile_stride : my_tb) + tile;
                 qb = tb[0];
@@ -451,10 +463,11 @@ __global__ void __launch_bounds__(TPB, WAVES_PER_EU) k_tail_select(const ST* __r
         }
     };
     // The drain: the pieces of a window (<= 64, 8 to a group), as ONE hand-scheduled asm statement per window.  A piece is
-    // one 64-lane load of 4-byte tail entries and one LDS-atomic instruction.  Written to the instruction: per piece 8 VALU
-    // (two v_readlane for the piece's start and factor, sign-extract / convert / multiply / convert of the Q0.16 rater-side
-    // value, two for the cell's byte address — the accumulator sits at LDS address 0 and the cell comes out of it_pack
-    // ready-made), 5 SALU, one buffer load, one ds_add.  The compiler's version of the same loop took 14 VALU per piece:
+    // one 64-lane load of 4-byte tail entries and one LDS-atomic instruction.  Written to the instruction: per piece 6 VALU
+    // (two v_readlane for the piece's start and factor; convert / multiply / convert-to-nearest of the rater-side word — used
+    // WHOLE, its address bits are pre-compensated in the value field, prep.hip: k_item_major — and ONE v_and for the cell's
+    // byte address: the accumulator sits at LDS address 0 and the address comes out of it_pack ready-made; round 2 spent 8:
+    // a sign-extraction of a 17-bit field and a shift + mask for the cell), 5 SALU, one buffer load, one ds_add.  The compiler's version of the same loop took 14 VALU per piece:
     // it paid a compare and a select per piece on both sides to keep lanes past the end of a piece harmless; here the
     // loads run unmasked (the entries behind a piece's end are mapped memory: the buffer descriptor covers the whole array
     // and answers 0 beyond it) and the atomics run under the piece's lane mask, set from the scalar unit
@@ -503,12 +516,10 @@ __global__ void __launch_bounds__(TPB, WAVES_PER_EU) k_tail_select(const ST* __r
     "s_add_u32 %[sj], %[sg], " #OFF "\n\t"                                 \
     "v_readlane_b32 %[sx], %[dx], %[sj]\n\t"                               \
     "s_waitcnt vmcnt(" #N ")\n\t"                                          \
-    "v_bfe_i32 %[t], %[" W "], 0, 17\n\t"                                  \
-    "v_cvt_f32_i32_e32 %[t], %[t]\n\t"                                     \
+    "v_cvt_f32_i32_e32 %[t], %[" W "]\n\t"                                 \
+    "v_and_b32_e32 %[a], 0xfffc, %[" W "]\n\t"                             \
     "v_mul_f32_e32 %[t], %[sx], %[t]\n\t"                                  \
-    "v_cvt_i32_f32_e32 %[t], %[t]\n\t"                                     \
-    "v_lshrrev_b32_e32 %[a], 15, %[" W "]\n\t"                             \
-    "v_and_b32_e32 %[a], 0x1fffc, %[a]\n\t"                                \
+    "v_cvt_rpi_i32_f32_e32 %[t], %[t]\n\t"                                 \
     "s_lshr_b64 exec, -1, %[sx]\n\t"                                       \
     KN_TAIL_ADD                                                            \
     "s_mov_b64 exec, -1\n\t"
@@ -852,7 +863,7 @@ void select_profile_dump() {
 #endif
 
 template <class ST, bool JAC>
-static void launch_tail_select_t(const TailArgs& T, const ST* S, bool s_by_user, int64_t lds, int32_t n_rows, const int32_t* d_row_user,
+static void launch_tail_select_t(const TailArgs& T, const ST* S, bool s_by_user, int64_t lds, int32_t n_rows, const int32_t* d_row_user, const int32_t* d_row_srow,
                                  int32_t U, int32_t kk, float eps_opnd, float eps_rest, int32_t cap, int32_t* cand_idx, float* cand_approx,
                                  int32_t* cand_cnt, float* cand_eps, int32_t* grp_v0, float* grp_x, int32_t gcap, bool anticipate, hipStream_t st) {
     const size_t smem = (size_t)TCOLS * 4 + (size_t)NBINS * 4 + (size_t)EMAX * 4 + 2 * ((size_t)EMAX * 12 + (size_t)PMAX * 2) + (2 * (TPB / 64) + 4 + 64) * 4;  // + 64 scratch cells
@@ -866,7 +877,7 @@ static void launch_tail_select_t(const TailArgs& T, const ST* S, bool s_by_user,
     const char* sg = getenv("KNNCF_DEBUG_ANTICIPATE_SIGMA");
     const float ant_sigma = !anticipate ? -1.0f : sg ? (float)atof(sg) : 7.0f;
 #endif
-    k_tail_select<ST, JAC><<<n_rows, TPB, smem, st>>>(S, s_by_user ? 1 : 0, lds, n_rows, d_row_user, T, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, ant_sigma);
+    k_tail_select<ST, JAC><<<n_rows, TPB, smem, st>>>(S, s_by_user ? 1 : 0, lds, n_rows, d_row_user, d_row_srow, T, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, ant_sigma);
     KN_HIP(hipGetLastError());
 #ifdef KNNCF_SELECT_PROFILE
     KN_HIP(hipStreamSynchronize(st));
@@ -877,7 +888,7 @@ static void launch_tail_select_t(const TailArgs& T, const ST* S, bool s_by_user,
 void launch_tail_select(const Train& tr, const int32_t* d_colmap, const TailEntries& te, bool has_tail, const void* S, bool s_by_user, bool s_fp16, int64_t lds,
                         int32_t n_rows, const int32_t* d_row_user, int32_t k, float eps_opnd, float eps_rest, int32_t cap,
                         int32_t* cand_idx, float* cand_approx, int32_t* cand_cnt, float* cand_eps, int32_t* grp_v0, float* grp_x,
-                        int32_t gcap, hipStream_t st, bool anticipate) {
+                        int32_t gcap, hipStream_t st, bool anticipate, const int32_t* d_row_srow) {
     if (n_rows <= 0) return;
     KN_REQUIRE(gcap >= 1024 && gcap % 8 == 0, KNNCF_E_INVALID, "select: group store too small");
     const int32_t U = tr.U;
@@ -893,11 +904,11 @@ void launch_tail_select(const Train& tr, const int32_t* d_colmap, const TailEntr
                te.cnt, te.item, te.x, te.tail_abs, te.head_sq, te.row_len};
     if (tr.jaccard) {
         KN_REQUIRE(te.row_len != nullptr, KNNCF_E_STATE, "select: row lengths missing");
-        if (s_fp16) launch_tail_select_t<_Float16, true>(T, static_cast<const _Float16*>(S), s_by_user, lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, anticipate, st);
-        else launch_tail_select_t<float, true>(T, static_cast<const float*>(S), s_by_user, lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, anticipate, st);
+        if (s_fp16) launch_tail_select_t<_Float16, true>(T, static_cast<const _Float16*>(S), s_by_user, lds, n_rows, d_row_user, d_row_srow, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, anticipate, st);
+        else launch_tail_select_t<float, true>(T, static_cast<const float*>(S), s_by_user, lds, n_rows, d_row_user, d_row_srow, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, anticipate, st);
     } else {
-        if (s_fp16) launch_tail_select_t<_Float16, false>(T, static_cast<const _Float16*>(S), s_by_user, lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, anticipate, st);
-        else launch_tail_select_t<float, false>(T, static_cast<const float*>(S), s_by_user, lds, n_rows, d_row_user, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, anticipate, st);
+        if (s_fp16) launch_tail_select_t<_Float16, false>(T, static_cast<const _Float16*>(S), s_by_user, lds, n_rows, d_row_user, d_row_srow, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, anticipate, st);
+        else launch_tail_select_t<float, false>(T, static_cast<const float*>(S), s_by_user, lds, n_rows, d_row_user, d_row_srow, U, kk, eps_opnd, eps_rest, cap, cand_idx, cand_approx, cand_cnt, cand_eps, grp_v0, grp_x, gcap, anticipate, st);
     }
 }
 

@@ -435,15 +435,22 @@ def test_wide_shape_takes_the_large_u_paths(kn, oracle, synth):
     e.close()
 
 
-def test_overshooting_anticipated_thresholds_are_caught(kn, synth, monkeypatch):
+@pytest.mark.parametrize("path", ["symmetric", "one_row_block", "row_blocks"])
+def test_overshooting_anticipated_thresholds_are_caught(kn, synth, monkeypatch, path):
     """select.hip emits against ANTICIPATED thresholds (rank k f + 7 sigma ... of the columns seen) and verifies them at the
     end of the row; with the margin cut to 2.5 sigma (test hook) the guess overshoots in some rows, the final check must
     notice, and those rows are rebuilt exactly: every neighbour list then still equals the default build's, which the
     full-size and wide-shape tests pin to the oracle.  With no margin at all the guess fails in a large part of the rows: the
     host then sends the marked rows through select + re-rank once more with the plain thresholds instead of through the
-    per-row exact path (no fallback row is left)."""
+    per-row exact path (no fallback row is left) — on the whole-matrix path, on the one-block row-block path that sharded
+    handles take, and per block when a capped workspace cuts the users into several row blocks (syn-1M's path)."""
     import torch
 
+    if path != "symmetric":
+        monkeypatch.setenv("KNNCF_DEBUG_NO_SYMMETRIC_GEMM", "1")
+    else:
+        monkeypatch.delenv("KNNCF_DEBUG_NO_SYMMETRIC_GEMM", raising=False)
+    workspace = (6 << 30) if path == "row_blocks" else 0      # ~16 k rows per block: six blocks
     d = synth.syn_scaled(90_000, 3_000, 3_000_000, seed=31, half_stars=True)   # six column tiles
     dev = torch.device("cuda", 0)
     tr = tuple(torch.from_numpy(a).to(dev) for a in (d.train.users, d.train.items, d.train.ratings))
@@ -454,16 +461,19 @@ def test_overshooting_anticipated_thresholds_are_caught(kn, synth, monkeypatch):
             monkeypatch.delenv("KNNCF_DEBUG_ANTICIPATE_SIGMA", raising=False)
         else:
             monkeypatch.setenv("KNNCF_DEBUG_ANTICIPATE_SIGMA", sigma)
-        e = kn.Engine(k=100, flags=kn.FLAG_VERIFY_BOUND)
+        e = kn.Engine(k=100, flags=kn.FLAG_VERIFY_BOUND, workspace_bytes=workspace)
         e.fit_device(*tr)
         ids, sims, counts = e.neighbors_batch(users)
         t = e.timings()
         assert t["max_bound_violation"] <= 0.0
         out[sigma] = (ids, sims, counts, t["fallback_rows"], t["select_launches"])
         e.close()
+    blocks = out[None][4]
+    assert blocks == (1 if path != "row_blocks" else blocks) and (path != "row_blocks" or blocks >= 3)
     assert out[None][3] == 0 and out["-1"][3] == 0        # 7 sigma / no anticipation: no row needs the fallback
     assert 0 < out["2.5"][3] < len(users) // 10           # the hook really produced overshoots, and not everywhere
-    assert out["0"][3] == 0 and out["0"][4] == out[None][4] + 1   # too many overshoots for the per-row path: one plain second pass
+    # too many overshoots for the per-row path: one plain second pass per block, no fallback row left
+    assert out["0"][3] == 0 and out["0"][4] == 2 * blocks
     for sigma in ("2.5", "0", "-1"):
         assert np.array_equal(out[sigma][0], out[None][0]) and np.array_equal(out[sigma][2], out[None][2])
         assert np.array_equal(out[sigma][1].view(np.int64), out[None][1].view(np.int64))
