@@ -92,11 +92,11 @@ def cpu_baseline(split, k, budget_s, n_test_total):
         "value": done_preds / (t_pred + share), "unit": "predictions/s", "cores": 1, "kind": "port",
         "sample": (f"oracle (C fp64 restatement of shared/predictions.scala, reference is single-threaded local[1]): "
                    f"first {n_users} test users = {done_preds} predictions in {t_pred:.1f} s after a {t_fit:.1f} s fit "
-                   f"(fit amortised over all {n_test_total} predictions); host has {os.cpu_count()} cores"),
+                   f"(fit amortised over all {n_test_total} predictions); host: {O.cpu_model()}, {os.cpu_count()} logical CPUs"),
     }
     # (2) the same closures in the oracle's bulk form (row-wise accumulation, one user per thread) on every core this
     # process may use: neighbour lists of the sample users, then their test rows
-    cores = O.host_threads()
+    cores = O.host_threads()  # every CPU this process may run on (no cap)
     all_cores = None
     try:
         done_preds, t_used, n_users = 0, 0.0, 0
@@ -116,7 +116,8 @@ def cpu_baseline(split, k, budget_s, n_test_total):
             "value": done_preds / (t_used + share), "unit": "predictions/s", "cores": cores, "kind": "port",
             "sample": (f"oracle bulk form (OpenMP, one user per thread; tests/test_oracle_bulk.py pins it bit for bit to the "
                        f"literal closures): first {n_users} test users = {done_preds} predictions in {t_used:.1f} s on {cores} "
-                       f"threads, same amortised single-threaded {t_fit:.1f} s fit"),
+                       f"threads = every CPU this process is allowed on ({O.cpu_model()}, {os.cpu_count()} logical CPUs on the host), "
+                       f"same amortised single-threaded {t_fit:.1f} s fit"),
         }
     except O.OracleError:
         pass  # a user with <= 4 ratings: the bulk form refuses (memo-history dependent)

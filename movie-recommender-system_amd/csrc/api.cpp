@@ -262,7 +262,9 @@ int32_t choose_head(knncf_handle* h, int32_t rows_total, bool symmetric) {
     } else if (h->cfg.head_items > 0) {
         H = (int32_t)std::min<int64_t>(h->cfg.head_items, I);
     } else {
-        // marginal rates measured on MI355X at the ml-25m shape (head sweeps 192 .. 1024, profiles/README.md): full-square
+        // marginal rates measured on MI355X at the ml-25m shape (head sweeps 192 .. 1024, profiles/README.md; re-measured in
+        // round 3 with the overlapped GEMM and the 6-VALU drain: 0.0195 ms per dense column on the symmetric path = 2.7e15
+        // full-square flops per second, 4.2e-13 s per tail pair product — the optimum stays at 384 / 256): full-square
         // flops per second bought by one more dense column — the symmetric launch computes half of them — and tail pair
         // products per second through k_tail_select
         const double RATE_DENSE = symmetric ? 2.8e15 : 1.2e15;
@@ -509,22 +511,47 @@ void build_neighbors(knncf_handle* h, int32_t count) {
         }
         KN_HIP(hipEventRecord(h->ev_produced[slot], sp));
         KN_HIP(hipStreamWaitEvent(sc, h->ev_produced[slot], 0));
-        {
+        TailEntries te{h->te_cnt.p, h->te_item.p, h->te_x.p, h->row_tail_abs.p, h->row_head_sq.p, h->row_len.p};
+        h->prep.join_commit(sc);  // the item-major rater lists and the tile table (second part of prep_commit)
+        const void* Sblk = use_sym ? (const void*)h->S_full.p : (const void*)h->S[slot].p;
+        const int32_t gcap = select_gcap(nt.k);
+        // rows [r0, r0 + nr) of this block through select (stream sc) / re-rank (stream sr): every per-row store is indexed by
+        // the launch row, so a part of the block is the same launch on offset pointers
+        auto select_rows = [&](int32_t r0, int32_t nr) {
             // sparse tail (LDS atomics per row tile) + histogram select, fused: one pass over S
             Stage s(h, &h->tm.select_ms, sc);
-            TailEntries te{h->te_cnt.p, h->te_item.p, h->te_x.p, h->row_tail_abs.p, h->row_head_sq.p, h->row_len.p};
-            h->prep.join_commit(sc);  // the item-major rater lists and the tile table (second part of prep_commit)
-            launch_tail_select(tr, h->colmap.p, te, head < tr.I, use_sym ? h->S_full.p : h->S[slot].p, use_sym, s_fp16, U_pad, rows, d_rows, nt.k, eps_opnd, eps_rest, cap,
-                               h->sel.cand_idx.p, h->sel.cand_approx.p, h->sel.cand_cnt.p, h->sel.cand_eps.p, h->sel.grp_v0.p, h->sel.grp_x.p, select_gcap(nt.k), sc);
+            const void* Sp = use_sym ? Sblk : (const void*)(static_cast<const char*>(Sblk) + (size_t)r0 * (size_t)U_pad * (size_t)s_elem);
+            launch_tail_select(tr, h->colmap.p, te, head < tr.I, Sp, use_sym, s_fp16, U_pad, nr, d_rows + r0, nt.k, eps_opnd, eps_rest, cap,
+                               h->sel.cand_idx.p + (size_t)r0 * cap, h->sel.cand_approx.p + (size_t)r0 * cap, h->sel.cand_cnt.p + r0, h->sel.cand_eps.p + r0,
+                               h->sel.grp_v0.p + (size_t)r0 * gcap, h->sel.grp_x.p + (size_t)r0 * gcap * 8, gcap, sc);
             h->tm.select_launches += 1;
-            h->tm.tail_pair_updates += h->tail_pairs_full * ((double)rows / (double)tr.U);
-            h->tm.select_row_bytes += (double)s_elem * (double)rows * (double)tr.U;
-        }
-        if (overlap && !per_block_redo) KN_HIP(hipEventRecord(h->ev_consumed[slot], sc));
-        {
-            Stage s(h, &h->tm.rerank_ms, sc);
-            launch_rerank(tr, nt, rows, d_rows, cap, h->sel.cand_idx.p, h->sel.cand_approx.p, h->sel.cand_cnt.p, h->sel.cand_eps.p,
-                          h->sel.stats.p, h->sel.row_entries.p, verify, sc);
+            h->tm.tail_pair_updates += h->tail_pairs_full * ((double)nr / (double)tr.U);
+            h->tm.select_row_bytes += (double)s_elem * (double)nr * (double)tr.U;
+        };
+        auto rerank_rows = [&](int32_t r0, int32_t nr, hipStream_t sr) {
+            Stage s(h, &h->tm.rerank_ms, sr);
+            launch_rerank(tr, nt, nr, d_rows + r0, cap, h->sel.cand_idx.p + (size_t)r0 * cap, h->sel.cand_approx.p + (size_t)r0 * cap, h->sel.cand_cnt.p + r0,
+                          h->sel.cand_eps.p + r0, h->sel.stats.p, h->sel.row_entries.p + r0, verify, sr);
+        };
+        // SPLIT LAUNCHES (one-block row-block builds: sharded handles).  One workgroup per row, rows longest first — but the
+        // re-rank of the few heaviest rows (their candidates are heavy raters too: up to 35 x the median row's work at the
+        // ml-25m shape, scripts/analysis/row_work_profile.py) outlasts a shard's whole launch: 1.5 - 3.2 ms per shard where the
+        // work is 1.4.  So the heaviest rows are selected first and their re-rank runs on the second stream UNDER the select
+        // of everybody else.  (A whole-matrix build's one launch hides that tail by itself.)
+        const int32_t n_heavy = (!use_sym && n_blocks == 1 && !overlap && rows >= 4096 && !getenv("KNNCF_DEBUG_NO_SPLIT_LAUNCH")) ? std::min<int32_t>(1024, rows / 8) : 0;
+        if (n_heavy > 0) {
+            select_rows(0, n_heavy);
+            KN_HIP(hipEventRecord(h->ev_ready, sc));
+            KN_HIP(hipStreamWaitEvent(h->stream2, h->ev_ready, 0));
+            rerank_rows(0, n_heavy, h->stream2);
+            KN_HIP(hipEventRecord(h->ev_produced[1], h->stream2));
+            select_rows(n_heavy, rows - n_heavy);
+            rerank_rows(n_heavy, rows - n_heavy, sc);
+            KN_HIP(hipStreamWaitEvent(sc, h->ev_produced[1], 0));  // join
+        } else {
+            select_rows(0, rows);
+            if (overlap && !per_block_redo) KN_HIP(hipEventRecord(h->ev_consumed[slot], sc));
+            rerank_rows(0, rows, sc);
         }
         if (!overlap) KN_HIP(hipEventRecord(h->ev_consumed[slot], sc));
         KN_HIP(hipMemcpyAsync(h->pinned_cnt + rb, h->sel.cand_cnt.p, rows * sizeof(int32_t), hipMemcpyDeviceToHost, sc));
@@ -1282,8 +1309,8 @@ int knncf_shard_view_get(knncf_handle* h, knncf_shard_view* out) {
         Train& tr = h->tr;
         out->user_begin = tr.own_lo;
         out->user_end = tr.own_hi;
-        out->nnz_begin = fetch(h, tr.u_ptr.p, tr.own_lo);
-        out->nnz_end = fetch(h, tr.u_ptr.p, tr.own_hi);
+        out->nnz_begin = tr.own_p0;  // (read back once by prep_fit: no device round trip per view)
+        out->nnz_end = tr.own_p1;
         out->num_users = tr.U;
         out->num_ratings = tr.n;
         out->d_user_avg = tr.user_avg.p;

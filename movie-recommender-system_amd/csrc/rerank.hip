@@ -540,17 +540,21 @@ void launch_rerank(const Train& tr, NeighborTable& nt, int32_t n_rows, const int
                    const int32_t* cand_idx, const float* cand_approx, const int32_t* cand_cnt, const float* cand_eps,
                    double* d_stats, uint32_t* d_row_entries, bool verify, hipStream_t st) {
     if (n_rows <= 0) return;
-    KN_REQUIRE(nt.kcap <= 1024, KNNCF_E_UNSUPPORTED, "k > 1024 is not supported by the re-rank kernel yet");
+    // (the shortlist tile must hold the running best k and the next chunk: 2 k; a 4096-entry tile is 113 KiB of LDS at the
+    // ml-25m shape's 59 047 items — the wall is the CU's 160 KiB, not a design limit: predict/kNN.scala:73 goes to k = 943)
+    KN_REQUIRE(nt.kcap <= 2048, KNNCF_E_UNSUPPORTED, "k > 2048 is not supported by the re-rank kernel (its shortlist tile lives in LDS)");
     Rows R{tr.u_ptr.p, tr.s_col.p, tr.s_t.p, tr.s_pre.p, (uint32_t)(tr.n * 4), (uint32_t)(tr.n * 8)};
     const float* apx = verify ? cand_approx : nullptr;
     if (tr.jaccard) {
         if (nt.kcap <= 384) launch_rerank_tile<512, true>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
         else if (nt.kcap <= 512) launch_rerank_tile<1024, true>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
-        else launch_rerank_tile<2048, true>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
+        else if (nt.kcap <= 1024) launch_rerank_tile<2048, true>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
+        else launch_rerank_tile<4096, true>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
     } else {
         if (nt.kcap <= 384) launch_rerank_tile<512, false>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
         else if (nt.kcap <= 512) launch_rerank_tile<1024, false>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
-        else launch_rerank_tile<2048, false>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
+        else if (nt.kcap <= 1024) launch_rerank_tile<2048, false>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
+        else launch_rerank_tile<4096, false>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
     }
 }
 

@@ -42,20 +42,29 @@ class DeviceEngineAdapter:
     def __init__(self, engine, device):
         self.engine = engine
         self.device = device
+        self._wrapped = {}  # (pointer, length) -> tensor view: the library keeps its buffers across re-fits of the same shape
 
     def fit_device(self, users, items, ratings):
         self.engine.fit_device(users, items, ratings)
 
+    def _wrap(self, ptr, n):
+        key = (int(ptr or 0), int(n))
+        t = self._wrapped.get(key)
+        if t is None:
+            if len(self._wrapped) > 64:
+                self._wrapped.clear()
+            t = self._wrapped[key] = wrap_device_f64(ptr, n, self.device)
+        return t
+
     def shard_tensors(self):
         v = self.engine.shard_view()
-        dev = self.device
         return {
             "user_range": (v.user_begin, v.user_end),
             "nnz_range": (v.nnz_begin, v.nnz_end),
-            "user_avg": wrap_device_f64(v.d_user_avg, v.num_users, dev),
-            "user_norm": wrap_device_f64(v.d_user_norm, v.num_users, dev),
-            "dev": wrap_device_f64(v.d_dev, v.num_ratings, dev),
-            "pre": wrap_device_f64(v.d_pre, v.num_ratings, dev),
+            "user_avg": self._wrap(v.d_user_avg, v.num_users),
+            "user_norm": self._wrap(v.d_user_norm, v.num_users),
+            "dev": self._wrap(v.d_dev, v.num_ratings),
+            "pre": self._wrap(v.d_pre, v.num_ratings),
         }
 
     def shard_commit(self):

@@ -256,13 +256,25 @@ def set_threads(n):
     lib().orc_set_threads(int(n))
 
 
-def host_threads(cap=64):
-    """Threads the bulk evaluation may use: the CPUs this process is allowed on (the GPU box hands out a share)."""
+def host_threads(cap=None):
+    """Threads the bulk evaluation may use: every CPU this process is allowed on (the GPU box hands out a share); cap, if
+    given, bounds it."""
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
-    return max(1, min(n, cap))
+    return max(1, n if cap is None else min(n, cap))
+
+
+def cpu_model():
+    """the host CPU's model name (for the baseline's `sample` text)"""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
 
 
 class KnnTable:

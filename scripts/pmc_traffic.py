@@ -10,8 +10,8 @@ import json
 import sys
 from collections import defaultdict
 
-KERNELS = {"k_tail_select": "k_tail_select", "k_gemm_nt_bf16": "k_gemm_nt_bf16", "k_rerank<": "k_rerank", "k_rerankI": "k_rerank",
-           "k_predict_knn_items": "k_predict_knn"}
+KERNELS = {"k_tail_select": "k_tail_select", "k_gemm_nt_ov": "k_gemm_nt_bf16", "k_gemm_nt_bf16": "k_gemm_nt_bf16", "k_rerank<": "k_rerank",
+           "k_rerankI": "k_rerank", "k_predict_knn_items": "k_predict_knn"}
 
 
 def per_kernel(path):
@@ -26,6 +26,7 @@ def per_kernel(path):
 
 def main():
     fetch, write, sq, out = sys.argv[1:5]
+    bench_line = sys.argv[5] if len(sys.argv) > 5 else None  # the bench line of one of the passes: names the head the cost model took
     f, w, s = per_kernel(fetch), per_kernel(write), per_kernel(sq)
     kernels = {}
     for name in ("k_tail_select", "k_gemm_nt_bf16", "k_rerank", "k_predict_knn"):
@@ -47,8 +48,15 @@ def main():
                 "lds_insts_per_wave_quadcycle": c["SQ_INSTS_LDS"] / wc,
             },
         }
+    workload = "syn-25m k=300 1 GPU, default flags (head_items by the cost model)"
+    if bench_line:
+        try:
+            d = json.loads(open(bench_line).read().strip().splitlines()[-1])
+            workload = f"{d['config']['workload']}, 1 GPU, default flags (head_items by the cost model: {int(d['hybrid']['head_items'])})"
+        except Exception:
+            pass
     doc = {
-        "workload": "syn-25m k=300 1 GPU, default flags (head_items by the cost model: 256)",
+        "workload": workload,
         "source": "rocprofv3 --pmc <one counter set per run> --kernel-trace, python3 bench.py --no-cpu-baseline --steps 1 --warmup 1",
         "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE (KB) reports half of the bytes of wide coalesced reads on gfx950 -> doubled; "
                       "WRITE_SIZE (KB) exact for 16-byte stores; narrow gathers uncalibrated. SQ_* counters: SQ_WAVE_CYCLES counts quad-cycles; "

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--k", type=int, default=300)
     ap.add_argument("--workload", default="syn-25m")
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--head-items", type=int, default=0, help="dense head width (0 = cost model)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "shard8_timings.json"))
     args = ap.parse_args()
     import torch
@@ -66,7 +67,7 @@ def main():
         single.close()  # (135 GB at this shape: the eight shard handles need the room)
         single = None
 
-    engines = {r: kn.Engine(k=args.k, shard_rank=r, shard_count=world) for r in ranks}
+    engines = {r: kn.Engine(k=args.k, shard_rank=r, shard_count=world, head_items=args.head_items) for r in ranks}
     report = []
     for p in range(args.passes):
         views, wall = {}, {r: 0.0 for r in ranks}

@@ -201,7 +201,8 @@ def test_jaccard_knn_beyond_the_personalized_table(kn, oracle, synth, symmetric,
     preds = e.predict_batch(kn.PRED_KNN, te[0], te[1])
     t = e.timings()
     assert t["max_bound_violation"] <= 0.0 and t["fallback_rows"] == 0
-    assert t["gemm_launches"] == (1 if symmetric else t["select_launches"])
+    # (one symmetric launch, or one row-block launch — whose select / re-rank come as two launches: heaviest rows first)
+    assert t["gemm_launches"] == 1 and t["select_launches"] == (1 if symmetric else 2)
     p = oracle.Model(*tr).pipeline(oracle.SIM_JACCARD, k)
     users = np.unique(d.train.users)
     sample = users[:: len(users) // 24]
@@ -466,14 +467,14 @@ def test_overshooting_anticipated_thresholds_are_caught(kn, synth, monkeypatch, 
         ids, sims, counts = e.neighbors_batch(users)
         t = e.timings()
         assert t["max_bound_violation"] <= 0.0
-        out[sigma] = (ids, sims, counts, t["fallback_rows"], t["select_launches"])
+        out[sigma] = (ids, sims, counts, t["fallback_rows"], t["select_launches"], t["gemm_launches"])
         e.close()
-    blocks = out[None][4]
-    assert blocks == (1 if path != "row_blocks" else blocks) and (path != "row_blocks" or blocks >= 3)
+    blocks = 1 if path == "symmetric" else out[None][5]  # row blocks of the build
+    assert blocks == 1 if path != "row_blocks" else blocks >= 3
     assert out[None][3] == 0 and out["-1"][3] == 0        # 7 sigma / no anticipation: no row needs the fallback
     assert 0 < out["2.5"][3] < len(users) // 10           # the hook really produced overshoots, and not everywhere
     # too many overshoots for the per-row path: one plain second pass per block, no fallback row left
-    assert out["0"][3] == 0 and out["0"][4] == 2 * blocks
+    assert out["0"][3] == 0 and out["0"][4] == out[None][4] + blocks
     for sigma in ("2.5", "0", "-1"):
         assert np.array_equal(out[sigma][0], out[None][0]) and np.array_equal(out[sigma][2], out[None][2])
         assert np.array_equal(out[sigma][1].view(np.int64), out[None][1].view(np.int64))
@@ -743,6 +744,33 @@ def test_sharded_fit_with_tiny_rows_equals_single_handle(kn, pkg, oracle, seed):
             assert count == len(tec[0])
             np.testing.assert_array_equal(preds.cpu().numpy(), opreds)
             assert total / count == pytest.approx(want, abs=1e-13)
+
+
+def test_k_beyond_1024(kn, oracle, synth):
+    """k = 1500 (the re-rank's 4096-entry shortlist tile, the k <= 2048 prediction kernel): neighbours and predictions against
+    the oracle on a 2 400-user shape; k = 2049 is refused loudly"""
+    d = synth.syn_scaled(2400, 500, 160_000, seed=41, half_stars=True, shuffle=True)
+    tr = (d.train.users, d.train.items, d.train.ratings)
+    te = (d.test.users[:4000], d.test.items[:4000], d.test.ratings[:4000])
+    k = 1500
+    p = oracle.Model(*tr).pipeline(oracle.SIM_COSINE, k)
+    want, preds = p.mae(*te, True)
+    e = kn.Engine(k=k, flags=kn.FLAG_VERIFY_BOUND)
+    e.fit(*tr)
+    np.testing.assert_array_equal(e.predict_batch(kn.PRED_KNN, te[0], te[1]), preds)
+    assert abs(e.mae(kn.PRED_KNN, *te) - want) <= MAE_TOL
+    assert e.timings()["max_bound_violation"] <= 0.0
+    for u in np.unique(d.test.users[:4000])[::97]:
+        ids, sims = e.neighbors(int(u))
+        oids, osims = p.neighbors(int(u))
+        assert len(ids) == k and ids.tolist() == oids.tolist() and sims.tolist() == osims.tolist()
+    e.close()
+    e = kn.Engine(k=2049)
+    e.fit(*tr)
+    with pytest.raises(kn.KnncfError) as ex:
+        e.mae(kn.PRED_KNN, *te)
+    assert ex.value.status == kn.E_UNSUPPORTED
+    e.close()
 
 
 def test_group_of_one_device_equals_plain_handle(kn, oracle, syn100k):
