@@ -38,7 +38,7 @@ HBM_PEAK_TBPS = 8.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # scripts/microbench/lds_atomic_rate.hip on MI355X: 9.6 random-address integer LDS lane-updates per clock per CU
 LDS_ATOMIC_UPDATES_PER_CLK_PER_CU = 9.6
 CUS, CLOCK_GHZ = 256, 2.4
-PMC_PROFILE = "r02_pmc_traffic_syn25m_1gpu.json"  # profiles/: the PMC passes of this exact workload (scripts/profile_round.sh)
+PMC_PROFILE = "r03_pmc_traffic_syn25m_1gpu.json"  # profiles/: the PMC passes of this exact workload (scripts/profile_round.sh)
 
 
 def log(*a):
@@ -255,7 +255,7 @@ def main():
         kernels = {
             # each UNORDERED pair once x 2 flops x the columns the dense part contracts (head_items); the kernel
             # executes the full square (both orders of every pair, padded tiles): executed_tflops beside it
-            "k_gemm_nt_bf16": roof("k_gemm_nt_bf16 (user x user similarity, dense head, MFMA)", "mfma", tm["gemm_ms"],
+            "k_gemm_nt_bf16": roof("k_gemm_nt_ov / k_gemm_nt_bf16 (user x user similarity, dense head, MFMA)", "mfma", tm["gemm_ms"],
                                    0.5 * tm["gemm_flops_algorithmic"], MFMA_BF16_DENSE_PEAK_TFLOPS, "TFLOP/s",
                                    "rows * (U-1) * head_items flops per launch = each unordered (row, user) pair once x 2 flops x head_items "
                                    "(SURVEY 8d with I_c -> the dense head; the sparse tail is k_tail_select's work)", launches=gemm_launches, key="k_gemm_nt_bf16"),
@@ -276,6 +276,15 @@ def main():
         g["executed_tflops"] = tm["gemm_flops_executed"] / (tm["gemm_ms"] / 1e3) / 1e12 if tm["gemm_ms"] > 0 else 0.0
         g["symmetric"] = tm["gemm_launches"] < tm["select_launches"]  # one launch computes the tiles on/above the diagonal and mirrors them
         g["executed_frac"] = g["executed_tflops"] / MFMA_BF16_DENSE_PEAK_TFLOPS
+        # the launch's other roof: it writes the whole similarity panel (both triangles on the symmetric path)
+        panel_bytes = tm["select_row_bytes"] / gemm_launches  # (what select reads is what the GEMM wrote: entry size x rows x users)
+        g["other_roofs"] = {"hbm_write": {"achieved": panel_bytes / (tm["gemm_ms"] / gemm_launches / 1e3) / 1e12 if tm["gemm_ms"] > 0 else 0.0, "peak": HBM_PEAK_TBPS,
+                                          "unit": "TB/s", "definition": "similarity panel bytes written per launch / launch time; a store-only kernel of the same "
+                                                                        "pattern writes 5.4 - 5.9 TB/s (scripts/microbench/store_pattern.hip): 9.0 ms for the 53 GB panel"}}
+        g["binding"] = ("the CU's vector-memory path: at K = 384 the launch is 9.0 ms of panel stores (what the K = 128 launch takes) plus 1.3 ms per k-step "
+                        "beyond the second — loads and stores do not overlap although nothing in the instruction stream orders them (one in-order pipe per CU, "
+                        "backed up by the HBM write rate); MFMA work hides under the loop's own overhead (ablations in DESIGN.md section 4); the north_star-literal "
+                        "dense formulation (all 59 047 columns) runs at 0.47 of the MFMA peak: profiles/r03_dense_all_syn25m_1gpu.json")
         # the tail's other roof: integer LDS atomics (one per tail pair product)
         ts = kernels["k_tail_select"]
         lds_peak = LDS_ATOMIC_UPDATES_PER_CLK_PER_CU * CUS * CLOCK_GHZ * 1e9
@@ -287,11 +296,13 @@ def main():
             "cache_level_bytes": {"achieved": (tm["select_row_bytes"] + 4.0 * tm["tail_pair_updates"]) / (tm["select_ms"] / 1e3) / 1e12 if tm["select_ms"] > 0 else 0.0,
                                   "unit": "TB/s", "definition": "panel bytes + 4 B per tail pair product (L2 / Infinity-Cache re-reads of the rater lists; NOT HBM bytes)"},
         }
-        ts["binding"] = ("latency / synchronisation, not a throughput roof: SQ pass of profiles/" + PMC_PROFILE + " — VALU issue ~54 % "
-                         "(0.135 instructions per wave-quad-cycle x 4 waves per SIMD), waves waiting 52 %; timing-only ablations "
-                         "of an earlier build of this kernel (DESIGN.md section 4; 35.6 ms at H = 256, 26.7 ms now): panel scan + thresholds 16.5 ms, "
-                         "tail set-up / read-out 4.4, tail drain 14.6 (6.2 of it loads + LDS atomics, 8.4 instruction issue at 8 VALU per "
-                         "64-entry piece); the provisional store's re-reads and its loose early thresholds have since been removed. "
+        ts["binding"] = ("neither throughput roof of the line: the kernel alternates a panel scan (HBM: 53 GB per step at ~4.6 TB/s when run "
+                         "alone, 11.5 ms) with the tail drain, which is bound by the Infinity Cache — ~3e8 pieces x 256 B = 77 GB per step out of "
+                         "the 80 MB rater-list array (it cannot live in the 4 MB L2s) at ~7 TB/s of the ~8.6 TB/s measured for uniformly gathered "
+                         "tables of that size.  Evidence (DESIGN.md section 4, profiles/README.md): timing-only ablations of the round-2 build at "
+                         "H = 384 (26.7 ms kernel): no tail machinery 11.5 ms, + tail set-up and read-out 15.6, + the drain 26.7; round 3 cut the "
+                         "drain from 8 to 6 VALU per piece and its marginal rate did not move (4.2e-13 s per pair product before and after, head "
+                         "sweeps 256 .. 640): not instruction issue.  SQ pass of profiles/" + PMC_PROFILE + ": VALU issue and waiting fractions. "
                          "HBM frac on compulsory bytes and the LDS-atomic frac are both reported")
         stage_of = {"k_gemm_nt_bf16": "gemm_ms", "k_tail_select": "select_ms", "k_rerank": "rerank_ms", "k_predict_knn": "predict_ms"}
         dominant = max(stage_of, key=lambda n: tm[stage_of[n]])
