@@ -94,13 +94,12 @@ def cpu_baseline(split, k, budget_s, n_test_total):
                    f"first {n_users} test users = {done_preds} predictions in {t_pred:.1f} s after a {t_fit:.1f} s fit "
                    f"(fit amortised over all {n_test_total} predictions); host: {O.cpu_model()}, {os.cpu_count()} logical CPUs"),
     }
-    # (2) the same closures in the oracle's bulk form (row-wise accumulation, one user per thread) on every core this
-    # process may use: neighbour lists of the sample users, then their test rows
-    cores = O.host_threads()  # every CPU this process may run on (no cap)
-    all_cores = None
-    try:
+    # (2) the same closures in the oracle's bulk form (row-wise accumulation, one user per thread).  Thread count: every CPU
+    # this process is allowed on — and, because a GPU box hands out a CPU SHARE that the affinity mask does not show (256
+    # threads on such a box ran at half the rate of 64), 64 threads as well; the faster of the two is reported with its count
+    def bulk_rate(cores):
         done_preds, t_used, n_users = 0, 0.0, 0
-        chunk = 256 * cores
+        chunk = 256 * min(cores, 64)
         while t_used < budget_s and n_users < len(order):
             users = order[n_users:n_users + chunk]
             mask = np.isin(te.users, users)
@@ -112,12 +111,23 @@ def cpu_baseline(split, k, budget_s, n_test_total):
             done_preds += int(mask.sum())
             n_users += len(users)
         share = t_fit * done_preds / max(1, n_test_total)
+        return done_preds / (t_used + share), done_preds, t_used, n_users
+
+    allowed = O.host_threads()
+    all_cores = None
+    try:
+        tried = {}
+        for cores in sorted({min(64, allowed), allowed}):
+            tried[cores] = bulk_rate(cores)
+        cores = max(tried, key=lambda c: tried[c][0])
+        rate, done_preds, t_used, n_users = tried[cores]
+        others = "; ".join(f"{c} threads: {tried[c][0]:.0f} predictions/s" for c in tried if c != cores)
         all_cores = {
-            "value": done_preds / (t_used + share), "unit": "predictions/s", "cores": cores, "kind": "port",
+            "value": rate, "unit": "predictions/s", "cores": cores, "kind": "port",
             "sample": (f"oracle bulk form (OpenMP, one user per thread; tests/test_oracle_bulk.py pins it bit for bit to the "
                        f"literal closures): first {n_users} test users = {done_preds} predictions in {t_used:.1f} s on {cores} "
-                       f"threads = every CPU this process is allowed on ({O.cpu_model()}, {os.cpu_count()} logical CPUs on the host), "
-                       f"same amortised single-threaded {t_fit:.1f} s fit"),
+                       f"threads ({O.cpu_model()}, {os.cpu_count()} logical CPUs on the host, {allowed} in this process's affinity mask"
+                       f"{'; also measured: ' + others if others else ''}), same amortised single-threaded {t_fit:.1f} s fit"),
         }
     except O.OracleError:
         pass  # a user with <= 4 ratings: the bulk form refuses (memo-history dependent)
