@@ -65,6 +65,7 @@ struct knncf_handle {
     int32_t* pinned_cnt = nullptr;
     size_t pinned_cap = 0;
     SelectScratch sel;
+    SliceScratch slices;
     NeighborTable pt;       // Personalized (no k): every non-zero similarity of every user (ids ascending, self included)
     bool pt_ready = false;
     DArr<int32_t> reco_users, reco_items, reco_out_items;
@@ -515,8 +516,8 @@ void build_neighbors(knncf_handle* h, int32_t count) {
         h->prep.join_commit(sc);  // the item-major rater lists and the tile table (second part of prep_commit)
         const void* Sblk = use_sym ? (const void*)h->S_full.p : (const void*)h->S[slot].p;
         const int32_t gcap = select_gcap(nt.k);
-        // rows [r0, r0 + nr) of this block through select (stream sc) / re-rank (stream sr): every per-row store is indexed by
-        // the launch row, so a part of the block is the same launch on offset pointers
+        // rows [r0, r0 + nr) of this block through select: every per-row store is indexed by the launch row, so a part of the
+        // block is the same launch on offset pointers
         auto select_rows = [&](int32_t r0, int32_t nr) {
             // sparse tail (LDS atomics per row tile) + histogram select, fused: one pass over S
             Stage s(h, &h->tm.select_ms, sc);
@@ -528,30 +529,27 @@ void build_neighbors(knncf_handle* h, int32_t count) {
             h->tm.tail_pair_updates += h->tail_pairs_full * ((double)nr / (double)tr.U);
             h->tm.select_row_bytes += (double)s_elem * (double)nr * (double)tr.U;
         };
-        auto rerank_rows = [&](int32_t r0, int32_t nr, hipStream_t sr) {
-            Stage s(h, &h->tm.rerank_ms, sr);
-            launch_rerank(tr, nt, nr, d_rows + r0, cap, h->sel.cand_idx.p + (size_t)r0 * cap, h->sel.cand_approx.p + (size_t)r0 * cap, h->sel.cand_cnt.p + r0,
-                          h->sel.cand_eps.p + r0, h->sel.stats.p, h->sel.row_entries.p + r0, verify, sr);
-        };
-        // SPLIT LAUNCHES (one-block row-block builds: sharded handles).  One workgroup per row, rows longest first — but the
-        // re-rank of the few heaviest rows (their candidates are heavy raters too: up to 35 x the median row's work at the
-        // ml-25m shape, scripts/analysis/row_work_profile.py) outlasts a shard's whole launch: 1.5 - 3.2 ms per shard where the
-        // work is 1.4.  So the heaviest rows are selected first and their re-rank runs on the second stream UNDER the select
-        // of everybody else.  (A whole-matrix build's one launch hides that tail by itself.)
-        const int32_t n_heavy = (!use_sym && n_blocks == 1 && !overlap && rows >= 4096 && !getenv("KNNCF_DEBUG_NO_SPLIT_LAUNCH")) ? std::min<int32_t>(1024, rows / 8) : 0;
-        if (n_heavy > 0) {
-            select_rows(0, n_heavy);
-            KN_HIP(hipEventRecord(h->ev_ready, sc));
-            KN_HIP(hipStreamWaitEvent(h->stream2, h->ev_ready, 0));
-            rerank_rows(0, n_heavy, h->stream2);
-            KN_HIP(hipEventRecord(h->ev_produced[1], h->stream2));
-            select_rows(n_heavy, rows - n_heavy);
-            rerank_rows(n_heavy, rows - n_heavy, sc);
-            KN_HIP(hipStreamWaitEvent(sc, h->ev_produced[1], 0));  // join
-        } else {
-            select_rows(0, rows);
-            if (overlap && !per_block_redo) KN_HIP(hipEventRecord(h->ev_consumed[slot], sc));
-            rerank_rows(0, rows, sc);
+        // HEAVY ROWS AS SLICES.  One workgroup per row, rows longest first — but the re-rank of the few heaviest rows (their
+        // candidates are heavy raters too: up to 33 x the median row's work at the ml-25m shape, 12 x at the 99.9th percentile,
+        // scripts/analysis/row_work_profile.py) outlasts a sharded handle's whole launch: 1.6 - 3.2 ms per shard of config 4 where
+        // the work is 1.4.  The top 0.2 % of such a block's rows are therefore re-ranked as P slices of their shortlists + a merge
+        // (rerank.hip), P workgroups per row in the same launch: 1.68 ms on every shard (scripts/slice_sweep.sh; 160 rows the
+        // same, 640 rows 1.83).  A whole-matrix launch hides that tail by itself, and there the slices' repeated row set-up
+        // only costs (+0.2 ms at 256 rows, +0.85 at 2048), so blocks beyond 65 536 rows go unsliced.
+        const int32_t slices = std::min<int32_t>(8, 8192 / std::max<int32_t>(nt.kcap, 1));
+        // (KNNCF_DEBUG_SLICE_ROWS = n: the first n rows of every block instead — 0 turns slicing off; the small-shape parity tests
+        // force it on with this)
+        const char* force_slices = getenv("KNNCF_DEBUG_SLICE_ROWS");
+        const int32_t n_heavy = slices < 2                         ? 0
+                                : force_slices                     ? std::max<int32_t>(0, std::min<int32_t>(rows, atoi(force_slices)))
+                                : (rows >= 4096 && rows <= 65536)  ? std::max<int32_t>(16, rows / 512)
+                                                                   : 0;
+        select_rows(0, rows);
+        if (overlap && !per_block_redo) KN_HIP(hipEventRecord(h->ev_consumed[slot], sc));
+        {
+            Stage s(h, &h->tm.rerank_ms, sc);
+            launch_rerank(tr, nt, rows, d_rows, cap, h->sel.cand_idx.p, h->sel.cand_approx.p, h->sel.cand_cnt.p, h->sel.cand_eps.p, h->sel.stats.p,
+                          h->sel.row_entries.p, verify, sc, n_heavy, slices, &h->slices);
         }
         if (!overlap) KN_HIP(hipEventRecord(h->ev_consumed[slot], sc));
         KN_HIP(hipMemcpyAsync(h->pinned_cnt + rb, h->sel.cand_cnt.p, rows * sizeof(int32_t), hipMemcpyDeviceToHost, sc));

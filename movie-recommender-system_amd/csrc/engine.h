@@ -205,11 +205,25 @@ void launch_tail_select(const Train& tr, const int32_t* d_colmap, const TailEntr
 // (d_row_srow: row-block panels — the panel row of launch row r when it is not r itself: the re-select of a subset of a block)
 // (anticipate = false: the emission thresholds are the plain k-th largest value seen so far — api.cpp re-runs the rows of a
 // build whose anticipated thresholds overshot too often that way)
-// exact fp64 similarities of the shortlists in reference order, stable top-k
+// the first n_heavy rows of a re-rank launch as P slices of their shortlists + a merge (rerank.hip)
+struct SliceScratch {
+    DArr<int32_t> part_idx, part_cnt;
+    DArr<uint32_t> entries;
+    DArr<double> part_sim;
+};
+struct Slices {  // (kernel argument)
+    int32_t n_heavy, P;
+    int32_t* part_idx;
+    double* part_sim;
+    int32_t* part_cnt;
+    uint32_t* entries;
+};
+// exact fp64 similarities of the shortlists in reference order, stable top-k; n_heavy > 0: the first n_heavy rows as `slices`
+// slices each (2 <= slices, slices * k <= 8192; sc holds their partial lists)
 void launch_rerank(const Train& tr, NeighborTable& nt, int32_t n_rows, const int32_t* d_row_user,
                    int32_t cap, const int32_t* cand_idx, const float* cand_approx,
                    const int32_t* cand_cnt, const float* cand_eps, double* d_stats, uint32_t* d_row_entries, bool verify,
-                   hipStream_t st);
+                   hipStream_t st, int32_t n_heavy = 0, int32_t slices = 1, SliceScratch* sc = nullptr);
 // exact similarities of one user against everyone (fallback + scalar queries)
 void launch_exact_row(const Train& tr, const NeighborTable& nt, int32_t user, int64_t user_seq,
                       double* d_out, hipStream_t st);

@@ -10,6 +10,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include <stdio.h>
 #include <string.h>
 
@@ -318,7 +320,11 @@ __global__ void __launch_bounds__(TPB, RerankPlan<TILE>::WAVES_PER_EU) k_rerank(
                                                 const int32_t* __restrict__ cand_cnt, int32_t kk, int32_t kcap,
                                                 int32_t* __restrict__ nbr_idx, double* __restrict__ nbr_sim,
                                                 int32_t* __restrict__ nbr_cnt, const float* __restrict__ cand_eps,
-                                                double* __restrict__ stats, uint32_t* __restrict__ row_entries_out, int32_t words) {
+                                                double* __restrict__ stats, uint32_t* __restrict__ row_entries_out, int32_t words,
+                                                const Slices sl) {
+    // the first sl.n_heavy rows come as sl.P SLICES of their shortlists each: workgroups [0, n_heavy * P) take slice
+    // (g % P) of row g / P and write its best k to row g of sl.part_* (partial lists, merged by k_merge_slices); the
+    // workgroups behind them take the other rows whole, as ever
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t part[TPB / 64];
     constexpr int WBUF = RerankPlan<TILE>::WBUF, UPRE_LDS = RerankPlan<TILE>::UPRE_LDS;
@@ -329,12 +335,23 @@ __global__ void __launch_bounds__(TPB, RerankPlan<TILE>::WAVES_PER_EU) k_rerank(
     u32x2* bp = reinterpret_cast<u32x2*>(sidx + TILE);         // [words] (bitmap word of u's items, items of u before it)
     uint32_t* wmeta = reinterpret_cast<uint32_t*>(bp + words);  // [TPB / 64][WMETA]
     __shared__ unsigned long long s_entries;
-    const int32_t r = blockIdx.x;
+    const int32_t g = blockIdx.x;
+    const int32_t n_sliced = sl.n_heavy * sl.P;
+    const bool sliced = g < n_sliced;
+    const int32_t r = sliced ? g / sl.P : g - n_sliced + sl.n_heavy;
     if (r >= n_rows) return;
-    const int32_t cnt = cand_cnt[r];
+    uint32_t* entries_out = sliced ? sl.entries + g : row_entries_out + r;
+    int32_t cnt = cand_cnt[r];
     if (cnt > cap) {  // overflow: the exact fallback redoes this row
-        if (threadIdx.x == 0) row_entries_out[r] = 0;
+        if (threadIdx.x == 0) *entries_out = 0;
         return;
+    }
+    int64_t cbase = (int64_t)r * cap;
+    if (sliced) {
+        const int32_t len = (cnt + sl.P - 1) / sl.P;
+        const int32_t c0 = min(cnt, (g - r * sl.P) * len);
+        cbase += c0;
+        cnt = min(len, cnt - c0);
     }
     if (threadIdx.x == 0) s_entries = 0;
 #ifdef KNNCF_RERANK_PROFILE
@@ -347,7 +364,7 @@ __global__ void __launch_bounds__(TPB, RerankPlan<TILE>::WAVES_PER_EU) k_rerank(
     const bool pre_lds = nu <= UPRE_LDS;
     // the wave's candidates of the first trip and their row extents: a chain of three dependent loads (count -> ids ->
     // extents) that is requested here so that it runs behind the set-up of u's bitmap instead of in front of the stream
-    const int32_t* my_cand = cand_idx + (int64_t)r * cap;
+    const int32_t* my_cand = cand_idx + cbase;
     int32_t v_first = 0;
     uint32_t b_first = 0, len_first = 0;
     {
@@ -429,7 +446,7 @@ __global__ void __launch_bounds__(TPB, RerankPlan<TILE>::WAVES_PER_EU) k_rerank(
             if (lane < n_c) {
                 ssim[best + c0 + lane] = s;
                 sidx[best + c0 + lane] = v;
-                if (cand_approx) worst = fmax(worst, fabs((double)cand_approx[(int64_t)r * cap + pos + c0 + lane] - s) - (double)eps);
+                if (cand_approx) worst = fmax(worst, fabs((double)cand_approx[cbase + pos + c0 + lane] - s) - (double)eps);
             }
         }
         RPH(1);  // exact similarities (this wave)
@@ -469,7 +486,7 @@ __global__ void __launch_bounds__(TPB, RerankPlan<TILE>::WAVES_PER_EU) k_rerank(
     for (int o = 32; o > 0; o >>= 1) row_entries += __shfl_xor(row_entries, o);
     if (lane == 0) atomicAdd(&s_entries, (unsigned long long)row_entries);  // LDS
     __syncthreads();
-    if (threadIdx.x == 0) row_entries_out[r] = (uint32_t)min(s_entries, 0xffffffffull);
+    if (threadIdx.x == 0) *entries_out = (uint32_t)min(s_entries, 0xffffffffull);
     if (cand_approx) {
         // max over the grid of (|approx - exact| - eps); must stay <= 0
         for (int o = 32; o > 0; o >>= 1) worst = fmax(worst, __shfl_xor(worst, o));
@@ -479,11 +496,13 @@ __global__ void __launch_bounds__(TPB, RerankPlan<TILE>::WAVES_PER_EU) k_rerank(
             atomicMax(w, (unsigned long long)__double_as_longlong(shifted));
         }
     }
+    int32_t* out_idx = sliced ? sl.part_idx + (int64_t)g * kcap : nbr_idx + (int64_t)u * kcap;
+    double* out_sim = sliced ? sl.part_sim + (int64_t)g * kcap : nbr_sim + (int64_t)u * kcap;
     for (int32_t j = threadIdx.x; j < best; j += TPB) {
-        nbr_idx[(int64_t)u * kcap + j] = sidx[j];
-        nbr_sim[(int64_t)u * kcap + j] = ssim[j];
+        out_idx[j] = sidx[j];
+        out_sim[j] = ssim[j];
     }
-    if (threadIdx.x == 0) nbr_cnt[u] = best;
+    if (threadIdx.x == 0) *(sliced ? sl.part_cnt + g : nbr_cnt + u) = best;
     RPH(4);  // output
 }
 
@@ -518,7 +537,7 @@ __global__ void __launch_bounds__(1024) k_sum_row_entries(int32_t n_rows, const 
 template <int TILE, bool JAC>
 static void launch_rerank_tile(const Rows& R, const Train& tr, NeighborTable& nt, int32_t n_rows, const int32_t* d_row_user,
                                int32_t cap, const int32_t* cand_idx, const float* cand_approx, const int32_t* cand_cnt,
-                               const float* cand_eps, double* d_stats, uint32_t* d_row_entries, hipStream_t st) {
+                               const float* cand_eps, double* d_stats, uint32_t* d_row_entries, hipStream_t st, const Slices& sl) {
     const int32_t words = (int32_t)ceil_div(tr.I, 32);
     constexpr int WBUF = RerankPlan<TILE>::WBUF, UPRE_LDS = RerankPlan<TILE>::UPRE_LDS;
     const size_t smem = (size_t)TILE * 8 + (size_t)UPRE_LDS * 8 + (size_t)(TPB / 64) * WBUF * 8 + (size_t)TILE * 4 +
@@ -526,8 +545,9 @@ static void launch_rerank_tile(const Rows& R, const Train& tr, NeighborTable& nt
     KN_REQUIRE(smem <= 160 * 1024 - 2048, KNNCF_E_UNSUPPORTED, "re-rank: item bitmap does not fit in LDS (too many items)");
     static PerDeviceState lds_state;
     ensure_dynamic_lds(lds_state, (const void*)k_rerank<TILE, JAC>, smem);
-    k_rerank<TILE, JAC><<<n_rows, TPB, smem, st>>>(R, nt.seq.p, n_rows, d_row_user, cap, cand_idx, cand_approx, cand_cnt, nt.kcap,
-                                              nt.kcap, nt.idx.p, nt.sim.p, nt.cnt.p, cand_eps, d_stats, d_row_entries, words);
+    const int32_t grid = n_rows + sl.n_heavy * (sl.P - 1);
+    k_rerank<TILE, JAC><<<grid, TPB, smem, st>>>(R, nt.seq.p, n_rows, d_row_user, cap, cand_idx, cand_approx, cand_cnt, nt.kcap,
+                                            nt.kcap, nt.idx.p, nt.sim.p, nt.cnt.p, cand_eps, d_stats, d_row_entries, words, sl);
     k_sum_row_entries<<<(unsigned)ceil_div(n_rows, 1024), 1024, 0, st>>>(n_rows, d_row_entries, reinterpret_cast<unsigned long long*>(d_stats) + 1);
     KN_HIP(hipGetLastError());
 #ifdef KNNCF_RERANK_PROFILE
@@ -536,25 +556,114 @@ static void launch_rerank_tile(const Rows& R, const Train& tr, NeighborTable& nt
 #endif
 }
 
+// ---- heavy rows as slices ---------------------------------------------------------------------------------------------
+// One workgroup per row is the wrong grain for the heaviest rows: their candidates are heavy raters too (up to 33 x the median
+// row's work at the ml-25m shape, scripts/analysis/row_work_profile.py), and one such row outlasts a sharded handle's whole
+// launch.  The first n_heavy rows of a launch (rows are ordered longest first) are therefore re-ranked as P SLICES of their
+// shortlists: P workgroups each return the best k of their slice — the best k of the whole shortlist is the best k of the
+// union of those — and k_merge_slices sorts the P partial lists into the row's final list with the same total order.
+template <int MT>  // entries sorted at a time (a power of two >= P * k)
+__global__ void __launch_bounds__(256) k_merge_slices(int32_t kk, int32_t kcap, int32_t cap, const int32_t* __restrict__ row_user,
+                                                      const int32_t* __restrict__ cand_cnt, const Slices sl,
+                                                      uint32_t* __restrict__ row_entries_out, int32_t* __restrict__ nbr_idx,
+                                                      double* __restrict__ nbr_sim, int32_t* __restrict__ nbr_cnt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* ssim = reinterpret_cast<double*>(smem);        // [MT]
+    int32_t* sidx = reinterpret_cast<int32_t*>(ssim + MT);  // [MT]
+    const int32_t r = blockIdx.x, P = sl.P;
+    if (r >= sl.n_heavy) return;
+    if (threadIdx.x == 0) {
+        uint64_t e = 0;
+        for (int32_t p = 0; p < P; ++p) e += sl.entries[r * P + p];
+        row_entries_out[r] = (uint32_t)min(e, (uint64_t)0xffffffffull);
+    }
+    if (cand_cnt[r] > cap) return;  // (overflow: the exact fallback writes this row)
+    const int32_t u = row_user[r];
+    int32_t total = 0;
+    for (int32_t p = 0; p < P; ++p) {
+        const int32_t c = sl.part_cnt[r * P + p];
+        for (int32_t j = threadIdx.x; j < c; j += 256) {
+            ssim[total + j] = sl.part_sim[(int64_t)(r * P + p) * kcap + j];
+            sidx[total + j] = sl.part_idx[(int64_t)(r * P + p) * kcap + j];
+        }
+        total += c;
+    }
+    for (int32_t j = total + threadIdx.x; j < MT; j += 256) {
+        ssim[j] = -INFINITY;
+        sidx[j] = 0x7fffffff;
+    }
+    __syncthreads();
+    for (int32_t size = 2; size <= MT; size <<= 1)
+        for (int32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int32_t t = threadIdx.x; t < (MT >> 1); t += 256) {
+                const int32_t lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const double sa = ssim[lo], sb = ssim[hi];
+                const int32_t ia = sidx[lo], ib = sidx[hi];
+                if (ranks_before(sa, ia, sb, ib) != up) {
+                    ssim[lo] = sb; ssim[hi] = sa;
+                    sidx[lo] = ib; sidx[hi] = ia;
+                }
+            }
+            __syncthreads();
+        }
+    const int32_t best = min(kk, total);
+    for (int32_t j = threadIdx.x; j < best; j += 256) {
+        nbr_idx[(int64_t)u * kcap + j] = sidx[j];
+        nbr_sim[(int64_t)u * kcap + j] = ssim[j];
+    }
+    if (threadIdx.x == 0) nbr_cnt[u] = best;
+}
+
+template <int MT>
+static void launch_merge(int32_t cap, const int32_t* d_row_user, const int32_t* cand_cnt, const Slices& sl, uint32_t* d_row_entries,
+                         NeighborTable& nt, hipStream_t st) {
+    static PerDeviceState lds_state;
+    const size_t smem = (size_t)MT * 12;
+    ensure_dynamic_lds(lds_state, (const void*)k_merge_slices<MT>, smem);
+    k_merge_slices<MT><<<sl.n_heavy, 256, smem, st>>>(nt.kcap, nt.kcap, cap, d_row_user, cand_cnt, sl, d_row_entries, nt.idx.p, nt.sim.p, nt.cnt.p);
+    KN_HIP(hipGetLastError());
+}
+
+// n_heavy > 0: the first n_heavy rows as `slices` slices each (2 <= slices, slices * k <= 8192; sc holds the partial lists)
 void launch_rerank(const Train& tr, NeighborTable& nt, int32_t n_rows, const int32_t* d_row_user, int32_t cap,
                    const int32_t* cand_idx, const float* cand_approx, const int32_t* cand_cnt, const float* cand_eps,
-                   double* d_stats, uint32_t* d_row_entries, bool verify, hipStream_t st) {
+                   double* d_stats, uint32_t* d_row_entries, bool verify, hipStream_t st, int32_t n_heavy, int32_t slices,
+                   SliceScratch* sc) {
     if (n_rows <= 0) return;
     // (the shortlist tile must hold the running best k and the next chunk: 2 k; a 4096-entry tile is 113 KiB of LDS at the
     // ml-25m shape's 59 047 items — the wall is the CU's 160 KiB, not a design limit: predict/kNN.scala:73 goes to k = 943)
     KN_REQUIRE(nt.kcap <= 2048, KNNCF_E_UNSUPPORTED, "k > 2048 is not supported by the re-rank kernel (its shortlist tile lives in LDS)");
+    Slices sl{0, 1, nullptr, nullptr, nullptr, nullptr};
+    if (n_heavy > 0) {
+        KN_REQUIRE(sc != nullptr && slices >= 2 && (int64_t)slices * nt.kcap <= 8192 && n_heavy <= n_rows, KNNCF_E_INVALID, "re-rank slices: bad arguments");
+        const size_t nv = (size_t)n_heavy * (size_t)slices, cells = nv * (size_t)std::max(nt.kcap, 1);
+        sc->entries.ensure(nv); sc->part_cnt.ensure(nv); sc->part_idx.ensure(cells); sc->part_sim.ensure(cells);
+        sl = Slices{n_heavy, slices, sc->part_idx.p, sc->part_sim.p, sc->part_cnt.p, sc->entries.p};
+    }
     Rows R{tr.u_ptr.p, tr.s_col.p, tr.s_t.p, tr.s_pre.p, (uint32_t)(tr.n * 4), (uint32_t)(tr.n * 8)};
     const float* apx = verify ? cand_approx : nullptr;
+#define KN_RERANK(TILEV, JACV) launch_rerank_tile<TILEV, JACV>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st, sl)
     if (tr.jaccard) {
-        if (nt.kcap <= 384) launch_rerank_tile<512, true>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
-        else if (nt.kcap <= 512) launch_rerank_tile<1024, true>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
-        else if (nt.kcap <= 1024) launch_rerank_tile<2048, true>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
-        else launch_rerank_tile<4096, true>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
+        if (nt.kcap <= 384) KN_RERANK(512, true);
+        else if (nt.kcap <= 512) KN_RERANK(1024, true);
+        else if (nt.kcap <= 1024) KN_RERANK(2048, true);
+        else KN_RERANK(4096, true);
     } else {
-        if (nt.kcap <= 384) launch_rerank_tile<512, false>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
-        else if (nt.kcap <= 512) launch_rerank_tile<1024, false>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
-        else if (nt.kcap <= 1024) launch_rerank_tile<2048, false>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
-        else launch_rerank_tile<4096, false>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, apx, cand_cnt, cand_eps, d_stats, d_row_entries, st);
+        if (nt.kcap <= 384) KN_RERANK(512, false);
+        else if (nt.kcap <= 512) KN_RERANK(1024, false);
+        else if (nt.kcap <= 1024) KN_RERANK(2048, false);
+        else KN_RERANK(4096, false);
+    }
+#undef KN_RERANK
+    if (n_heavy > 0) {
+        int32_t mt = 512;
+        while (mt < slices * nt.kcap) mt <<= 1;
+        if (mt <= 512) launch_merge<512>(cap, d_row_user, cand_cnt, sl, d_row_entries, nt, st);
+        else if (mt <= 1024) launch_merge<1024>(cap, d_row_user, cand_cnt, sl, d_row_entries, nt, st);
+        else if (mt <= 2048) launch_merge<2048>(cap, d_row_user, cand_cnt, sl, d_row_entries, nt, st);
+        else if (mt <= 4096) launch_merge<4096>(cap, d_row_user, cand_cnt, sl, d_row_entries, nt, st);
+        else launch_merge<8192>(cap, d_row_user, cand_cnt, sl, d_row_entries, nt, st);
     }
 }
 

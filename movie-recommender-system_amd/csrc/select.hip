@@ -56,7 +56,10 @@ static constexpr int CPT = TCOLS / TPB;  // columns per thread per tile (32 = 4 
 static constexpr int NG = CPT / 8;
 static_assert(CPT <= 32, "the survivor mask of a thread is one 32-bit word");
 static constexpr int EMAX = 256;     // row positions whose tail entries (16 B each) are held in LDS at a time
-static constexpr int PMAX = 1024;    // pieces per (chunk, tile) with a direct piece -> entry table in LDS
+#ifndef KNNCF_PMAX
+#define KNNCF_PMAX 1024
+#endif
+static constexpr int PMAX = KNNCF_PMAX;    // pieces per (chunk, tile) with a direct piece -> entry table in LDS (A/B switch: 0 = always the binary search)
 static constexpr int MAXT = TCOLS >= 16384 ? 12 : 24;  // tiles whose per-entry rater counts are packed into registers (12 x 16 384 columns: up to 196 608 users)
 static constexpr int WAVES_PER_EU = TCOLS >= 16384 ? 4 : 6;  // two / three 512-thread workgroups per CU (LDS: 79 / 47 KiB each)
 static constexpr int TAIL_G = 8;           // pieces per group of the drain (two groups in flight per wave)

@@ -201,8 +201,7 @@ def test_jaccard_knn_beyond_the_personalized_table(kn, oracle, synth, symmetric,
     preds = e.predict_batch(kn.PRED_KNN, te[0], te[1])
     t = e.timings()
     assert t["max_bound_violation"] <= 0.0 and t["fallback_rows"] == 0
-    # (one symmetric launch, or one row-block launch — whose select / re-rank come as two launches: heaviest rows first)
-    assert t["gemm_launches"] == 1 and t["select_launches"] == (1 if symmetric else 2)
+    assert t["gemm_launches"] == 1 and t["select_launches"] == 1
     p = oracle.Model(*tr).pipeline(oracle.SIM_JACCARD, k)
     users = np.unique(d.train.users)
     sample = users[:: len(users) // 24]
@@ -771,6 +770,43 @@ def test_k_beyond_1024(kn, oracle, synth):
         e.mae(kn.PRED_KNN, *te)
     assert ex.value.status == kn.E_UNSUPPORTED
     e.close()
+
+
+@pytest.mark.parametrize("case", ["cosine", "jaccard", "k1500", "empty_slices"])
+def test_heavy_rows_reranked_as_slices(kn, oracle, synth, syn100k, monkeypatch, case):
+    """the heaviest rows of a row block are re-ranked as P slices of their shortlists + a merge (rerank.hip; on by itself for
+    blocks of 4096 .. 65 536 rows: the eight-shard test of the ml-25m shape runs it that way): forced on here for the first
+    200 rows — or for ALL rows, where most slices of the short shortlists are empty — and compared on every third user with
+    the oracle, lists and predictions bit for bit"""
+    monkeypatch.setenv("KNNCF_DEBUG_SLICE_ROWS", "100000" if case == "empty_slices" else "200")
+    if case == "k1500":
+        d = synth.syn_scaled(2400, 500, 160_000, seed=43, half_stars=True, shuffle=True)
+        tr = (d.train.users, d.train.items, d.train.ratings)
+        te = (d.test.users[:4000], d.test.items[:4000], d.test.ratings[:4000])
+        ks, sim_o, sim_k = (1500,), oracle.SIM_COSINE, kn.SIM_COSINE
+    else:
+        d = syn100k
+        tr = (d.train.users, d.train.items, d.train.ratings)
+        te = (d.test.users, d.test.items, d.test.ratings)
+        ks = (3, 300, 943) if case != "jaccard" else (50,)
+        sim_o, sim_k = (oracle.SIM_JACCARD, kn.SIM_JACCARD) if case == "jaccard" else (oracle.SIM_COSINE, kn.SIM_COSINE)
+    m = oracle.Model(*tr)
+    users = np.unique(tr[0])
+    for k in ks:
+        e = _engine(kn, tr, k=k, sim=sim_k, flags=kn.FLAG_VERIFY_BOUND)
+        p = m.pipeline(sim_o, k)
+        want, preds = p.mae(*te, True)
+        np.testing.assert_array_equal(e.predict_batch(kn.PRED_KNN, te[0], te[1]), preds)
+        assert abs(e.mae(kn.PRED_KNN, *te) - want) <= MAE_TOL
+        ids, sims, counts = e.neighbors_batch(users[::3])
+        for row, u in enumerate(users[::3]):
+            oids, osims = p.neighbors(int(u))
+            assert counts[row] == len(oids), f"user {u} k {k}"
+            assert ids[row, : counts[row]].tolist() == oids.tolist(), f"user {u} k {k}"
+            assert sims[row, : counts[row]].tolist() == osims.tolist()
+        t = e.timings()
+        assert t["max_bound_violation"] <= 0.0 and t["fallback_rows"] == 0
+        e.close()
 
 
 def test_group_of_one_device_equals_plain_handle(kn, oracle, syn100k):
