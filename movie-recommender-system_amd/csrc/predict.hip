@@ -417,6 +417,15 @@ __global__ void __launch_bounds__(WAVES * 64) k_predict_knn_rows(PredArgs A, int
     }
 }
 
+#ifndef KNNCF_PRED_CHUNK
+#define KNNCF_PRED_CHUNK 64  // test rows per workgroup of k_predict_knn_items (A/B switch; at most 256)
+#endif
+#ifdef KNNCF_PREDICT_PROFILE  /* in-kernel cycle counters of k_predict_knn_items' phases (thread 0 of every workgroup) */
+__device__ unsigned long long g_pphase[8];
+#define PPH(i) do { if (threadIdx.x == 0) { const long long now_ = clock64(); atomicAdd(&g_pphase[i], (unsigned long long)(now_ - ph_t)); ph_t = now_; } } while (0)
+#else
+#define PPH(i) do {} while (0)
+#endif
 // ---- the item-grouped kNN prediction kernel -------------------------------------------------------------------------
 // Probing a rater bitmap in global memory costs one cache sector per neighbour: k = 300 probes touch nearly every line
 // of the item's 20 KB bitmap row, ~38 KB of L2 -> L1 traffic per prediction, and the kernels above are bound by exactly
@@ -430,8 +439,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_predict_knn_items(PredArgs A, in
                                                               const uint32_t* __restrict__ order, double* __restrict__ pred,
                                                               double* __restrict__ abs_err, uint8_t* __restrict__ owned,
                                                               int unknown_owned) {
-    constexpr int CAP = TR * 64;
-    constexpr int CHUNK = 64;  // rows per workgroup
+    constexpr int CAP = TR * 64;  // matches of a row: up to kcap
+    // matches whose (deviation, similarity) sit in LDS at a time: a row's matches are ordered and folded in windows of MCAP
+    // (~14 matches on the ml-25m shape; more than 64 for the rows of the few most-rated items only).  The buffers of a full
+    // CAP per wave (26 KB per workgroup at k = 300) held the kernel at three workgroups per CU; with 9 KB it runs four, and
+    // it waits on gather latency most of the time: 7.25 -> 6.3 ms
+    constexpr int MCAP = 64;
+    constexpr int CHUNK = KNNCF_PRED_CHUNK;  // rows per workgroup
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ibw = (int)A.ib_words;
     const int ibw2 = (ibw + 1) >> 1;  // pairs of bitmap words
@@ -439,9 +453,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_predict_knn_items(PredArgs A, in
     // comes with the same 16-byte LDS read): 25 instead of 30 KB, which is what lets a third workgroup onto the CU
     unsigned long long* bits = reinterpret_cast<unsigned long long*>(smem);              // [2 * ibw2]
     uint32_t* rnk = reinterpret_cast<uint32_t*>(bits + 2 * ibw2);                         // [ibw2] raters before word 2 j
-    double* m_dev = reinterpret_cast<double*>(rnk + ((ibw2 + 1) & ~1));                   // [WAVES][CAP]
-    double* m_sim = m_dev + WAVES * CAP;                                                  // [WAVES][CAP]
-    uint32_t* m_t = reinterpret_cast<uint32_t*>(m_sim + WAVES * CAP);                     // [WAVES][CAP]
+    double* m_dev = reinterpret_cast<double*>(rnk + ((ibw2 + 1) & ~1));                   // [WAVES][MCAP]
+    double* m_sim = m_dev + WAVES * MCAP;                                                 // [WAVES][MCAP]
+    uint32_t* m_t = reinterpret_cast<uint32_t*>(m_sim + WAVES * MCAP);                    // [WAVES][CAP] file rows of the matches
     __shared__ int64_t s_row[CHUNK];
     __shared__ int32_t s_u[CHUNK], s_i[CHUNK], s_cnt[CHUNK];
     __shared__ uint32_t s_rb[CHUNK];
@@ -451,9 +465,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_predict_knn_items(PredArgs A, in
     const int64_t r0 = (int64_t)blockIdx.x * CHUNK;
     if (r0 >= n) return;
     const int nr = (int)min((int64_t)CHUNK, n - r0);
+#ifdef KNNCF_PREDICT_PROFILE
+    long long ph_t = clock64();
+#endif
     uint32_t* mt = m_t + wave * CAP;
-    double* md = m_dev + wave * CAP;
-    double* ms = m_sim + wave * CAP;
+    double* md = m_dev + wave * MCAP;
+    double* ms = m_sim + wave * MCAP;
     if ((int)threadIdx.x < nr) {
         const int l = threadIdx.x;
         const int64_t row = order[r0 + l];
@@ -470,6 +487,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_predict_knn_items(PredArgs A, in
         s_active[l] = (mine && ua >= 0.0 && i >= 0 && cnt > 0 && len > 0) ? 1 : 0;
     }
     __syncthreads();
+    PPH(0);  // the rows' own data
     const auto r_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(A.it_t), 0, A.n_bytes4, 0x00020000);
     const auto r_dev = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(A.it_dev), 0, A.n_bytes4 * 2, 0x00020000);
     typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
@@ -482,11 +500,36 @@ __global__ void __launch_bounds__(WAVES * 64) k_predict_knn_items(PredArgs A, in
         if (any) {
             const unsigned long long* gb = A.item_bits + (int64_t)item * ibw;
             const uint32_t* gr = A.item_rank + (int64_t)item * ibw;
-            for (int w = threadIdx.x; w < 2 * ibw2; w += WAVES * 64) {
-                bits[w] = w < ibw ? gb[w] : 0ull;
-                if ((w & 1) == 0) rnk[w >> 1] = gr[w];
+            // every load of a batch is requested before the first is used (six bitmap words and three rank words per thread
+            // and batch: two batches at the ml-25m shape).  One word per trip of a plain loop paid ten dependent global
+            // latencies per run — a third of the kernel's time by its phase counters (scripts/predict_phase_profile.sh)
+            constexpr int NT = WAVES * 64;
+            for (int w0 = 0; w0 < 2 * ibw2; w0 += 6 * NT) {
+                unsigned long long bv[6];
+                uint32_t rv[3];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    const int w = w0 + q * NT + (int)threadIdx.x;
+                    bv[q] = w < ibw ? gb[w] : 0ull;
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int j = (w0 >> 1) + q * NT + (int)threadIdx.x;
+                    rv[q] = 2 * j < ibw ? gr[2 * j] : 0u;
+                }
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    const int w = w0 + q * NT + (int)threadIdx.x;
+                    if (w < 2 * ibw2) bits[w] = bv[q];
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int j = (w0 >> 1) + q * NT + (int)threadIdx.x;
+                    if (j < ibw2) rnk[j] = rv[q];
+                }
             }
             __syncthreads();
+            PPH(1);  // the item's bitmap + ranks into LDS
             for (int rg = ra + wave * G; rg < rbn; rg += WAVES * G) {  // G rows of the run per wave and trip
                 int rows[G];
                 int32_t cnts[G];
@@ -511,6 +554,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_predict_knn_items(PredArgs A, in
                         x[g][k] = __builtin_amdgcn_raw_buffer_load_b32(r_uidx, (int)(j * 4u), 0, 0);
                     }
                 }
+#ifdef KNNCF_PREDICT_PROFILE
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                PPH(2);  // the rows' neighbour ids have arrived
+#endif
                 u32x2 dv[G][TR];
                 uint32_t mtv[G][TR];
                 unsigned long long fmask[G][TR];
@@ -533,25 +580,34 @@ __global__ void __launch_bounds__(WAVES * 64) k_predict_knn_items(PredArgs A, in
                         // with the ratings instead of streamed with the ids (a third of the list bytes instead of all)
                         sv[g][k] = __builtin_amdgcn_raw_buffer_load_b64(r_usim[g], f ? (int)((64u * k + lane) * 8u) : -1, 0, 0);
                     }
+#ifdef KNNCF_PREDICT_PROFILE
+                PPH(3);  // probes issued
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                PPH(4);  // the matched ratings have arrived
+#endif
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     if (rows[g] < 0) continue;  // (wave-uniform)
                     int32_t total = 0;
 #pragma unroll
-                    for (int k = 0; k < TR; ++k) {
-                        const unsigned long long hit = fmask[g][k];
-                        if ((hit >> lane) & 1ull) {
-                            const int32_t slot = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(hit >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hit, 0u));
-                            mt[slot] = mtv[g][k];
-                            md[slot] = __hiloint2double((int)dv[g][k].y, (int)dv[g][k].x);
-                            ms[slot] = __hiloint2double((int)sv[g][k].y, (int)sv[g][k].x);
-                        }
-                        total += __popcll(hit);
-                    }
+                    for (int k = 0; k < TR; ++k) total += __popcll(fmask[g][k]);
                     if (total == 0) continue;  // no neighbour rated the item: the prediction is the user's mean (preset)
-                    // order the matches by training file row (the order of ratedI(i) :508-517): rank by counting
-                    if (total <= 64) {
+                    // order the matches by training file row (the order of ratedI(i) :508-517) — rank by counting — and fold
+                    double num = 0.0, den = 0.0;
+                    if (total <= MCAP) {
                         // the common case (~14 matches): one match per lane, the keys travel by v_readlane
+                        int32_t seen = 0;
+#pragma unroll
+                        for (int k = 0; k < TR; ++k) {
+                            const unsigned long long hit = fmask[g][k];
+                            if ((hit >> lane) & 1ull) {
+                                const int32_t slot = seen + __builtin_amdgcn_mbcnt_hi((uint32_t)(hit >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hit, 0u));
+                                mt[slot] = mtv[g][k];
+                                md[slot] = __hiloint2double((int)dv[g][k].y, (int)dv[g][k].x);
+                                ms[slot] = __hiloint2double((int)sv[g][k].y, (int)sv[g][k].x);
+                            }
+                            seen += __popcll(hit);
+                        }
                         wave_sync();
                         uint32_t key = 0xffffffffu, rk = 0;
                         double kd = 0.0, ks = 0.0;
@@ -559,42 +615,63 @@ __global__ void __launch_bounds__(WAVES * 64) k_predict_knn_items(PredArgs A, in
                         for (int32_t c = 0; c < total; ++c) rk += (uint32_t)((uint32_t)__builtin_amdgcn_readlane((int)key, c) < key);
                         if (lane < total) { md[rk] = kd; ms[rk] = ks; }
                         wave_sync();
+                        for (int32_t c = 0; c < total; ++c) {  // every lane folds the same sequence (LDS broadcast)
+                            const double sc = ms[c];
+                            num = num + md[c] * sc;
+                            den = den + fabs(sc);
+                        }
+                        wave_sync();
                     } else {
+                        // many matches (rows of the most-rated items): the file rows of all of them in LDS, every match
+                        // ranked where it sits (its trip's registers), then windows of MCAP ranks through the buffers
+                        int32_t seen = 0;
+#pragma unroll
+                        for (int k = 0; k < TR; ++k) {
+                            const unsigned long long hit = fmask[g][k];
+                            if ((hit >> lane) & 1ull)
+                                mt[seen + __builtin_amdgcn_mbcnt_hi((uint32_t)(hit >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hit, 0u))] = mtv[g][k];
+                            seen += __popcll(hit);
+                        }
                         for (int32_t c = total + lane; c < ((total + 3) & ~3); c += 64) mt[c] = 0xffffffffu;
                         wave_sync();
-                        uint32_t key[TR], rank[TR];
-                        double kd[TR], ks[TR];
-    #pragma unroll
-                        for (int k = 0; k < TR; ++k) {
-                            const int32_t slot = 64 * k + lane;
-                            rank[k] = 0; key[k] = 0; kd[k] = 0.0; ks[k] = 0.0;
-                            if (slot < total) { key[k] = mt[slot]; kd[k] = md[slot]; ks[k] = ms[slot]; }
-                        }
-                        const int nslot = (total + 63) >> 6;
+                        uint32_t rank[TR];
+#pragma unroll
+                        for (int k = 0; k < TR; ++k) rank[k] = 0;
                         const uint4* keys4 = reinterpret_cast<const uint4*>(mt);
                         for (int32_t c = 0; c < ((total + 3) >> 2); ++c) {
                             const uint4 kq = keys4[c];
-    #pragma unroll
-                            for (int k = 0; k < TR; ++k)
-                                if (k < nslot) rank[k] += (uint32_t)(kq.x < key[k]) + (uint32_t)(kq.y < key[k]) + (uint32_t)(kq.z < key[k]) + (uint32_t)(kq.w < key[k]);
+#pragma unroll
+                            for (int k = 0; k < TR; ++k) {
+                                const uint32_t key = mtv[g][k];
+                                rank[k] += (uint32_t)(kq.x < key) + (uint32_t)(kq.y < key) + (uint32_t)(kq.z < key) + (uint32_t)(kq.w < key);
+                            }
                         }
-    #pragma unroll
-                        for (int k = 0; k < TR; ++k)
-                            if (64 * k + lane < total) { md[rank[k]] = kd[k]; ms[rank[k]] = ks[k]; }
-                        wave_sync();
+                        for (int32_t b0 = 0; b0 < total; b0 += MCAP) {
+#pragma unroll
+                            for (int k = 0; k < TR; ++k) {
+                                const uint32_t at = rank[k] - (uint32_t)b0;
+                                if (((fmask[g][k] >> lane) & 1ull) && at < (uint32_t)MCAP) {
+                                    md[at] = __hiloint2double((int)dv[g][k].y, (int)dv[g][k].x);
+                                    ms[at] = __hiloint2double((int)sv[g][k].y, (int)sv[g][k].x);
+                                }
+                            }
+                            wave_sync();
+                            const int32_t nw = min(MCAP, total - b0);
+                            for (int32_t c = 0; c < nw; ++c) {
+                                const double sc = ms[c];
+                                num = num + md[c] * sc;
+                                den = den + fabs(sc);
+                            }
+                            wave_sync();
+                        }
                     }
-                    double num = 0.0, den = 0.0;
-                    for (int32_t c = 0; c < total; ++c) {  // every lane folds the same sequence (LDS broadcast)
-                        const double sc = ms[c];
-                        num = num + md[c] * sc;
-                        den = den + fabs(sc);
-                    }
-                    wave_sync();
                     const double wsd = (den > 0) ? num / den : 0.0;
                     if (lane == 0) s_p[rows[g]] = combine(s_ua[rows[g]], wsd);
                 }
+                PPH(5);  // order by file row + fold
             }
             __syncthreads();  // the bitmap is overwritten by the next run
+            PPH(6);  // wait for the other waves
         }
         ra = rbn;
     }
@@ -612,7 +689,23 @@ __global__ void __launch_bounds__(WAVES * 64) k_predict_knn_items(PredArgs A, in
             abs_err[row] = 0.0;
         }
     }
+    PPH(7);  // output
 }
+
+#ifdef KNNCF_PREDICT_PROFILE
+static void predict_profile_dump() {
+    unsigned long long h[8];
+    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pphase), sizeof(h));
+    unsigned long long tot = 0;
+    for (int i = 0; i < 8; ++i) tot += h[i];
+    static const char* names[8] = {"row data", "bitmap", "ids wait", "probe issue", "gather wait", "rank+fold", "barrier", "output"};
+    fprintf(stderr, "[predict profile] total %.3e cycles:", (double)tot);
+    for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * (double)h[i] / (double)tot);
+    fprintf(stderr, "\n");
+    memset(h, 0, sizeof(h));
+    hipMemcpyToSymbol(HIP_SYMBOL(g_pphase), h, sizeof(h));
+}
+#endif
 
 // sort key of a test row: its dense user / item (unknown ones last)
 __global__ void k_user_keys(int64_t n, const int32_t* __restrict__ du, uint32_t limit, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
@@ -710,11 +803,11 @@ void launch_predict(const Train& tr, const NeighborTable* nt, int predictor, int
         if (d_order && order_by_item && tr.ib_words > 0 && tr.ib_words * 12 <= 48 * 1024 && nt->kcap <= 512) {
             A.n_bytes4 = (uint32_t)(tr.n * 4);
             const int trips = (nt->kcap + 63) / 64;
-            const unsigned blocks = (unsigned)ceil_div(n, 64);
+            const unsigned blocks = (unsigned)ceil_div(n, KNNCF_PRED_CHUNK);
 #define KN_LAUNCH_ITEMS(TRV, GV)                                                                                          \
     do {                                                                                                                  \
         const size_t ibw2 = (size_t)(tr.ib_words + 1) / 2;                                                                  \
-        const size_t smem = ibw2 * 16 + ((ibw2 + 1) & ~(size_t)1) * 4 + (size_t)4 * (TRV * 64) * 20;                        \
+        const size_t smem = ibw2 * 16 + ((ibw2 + 1) & ~(size_t)1) * 4 + (size_t)4 * (64 * 16 + (TRV * 64) * 4);               \
         KN_HIP(hipFuncSetAttribute((const void*)k_predict_knn_items<TRV, GV, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
         k_predict_knn_items<TRV, GV, 4><<<blocks, 256, smem, st>>>(A, n, d_du, d_di, d_ratings, d_order, d_pred, d_abs_err,  \
                                                                   d_owned, unknown_users_owned ? 1 : 0);                \
@@ -726,6 +819,10 @@ void launch_predict(const Train& tr, const NeighborTable* nt, int predictor, int
             else KN_LAUNCH_ITEMS(8, 1);
 #undef KN_LAUNCH_ITEMS
             KN_HIP(hipGetLastError());
+#ifdef KNNCF_PREDICT_PROFILE
+            KN_HIP(hipStreamSynchronize(st));
+            predict_profile_dump();
+#endif
             return;
         }
         if (d_order && !order_by_item && tr.ib_words > 0 && bits_total < 4.0e9 && nt->kcap <= 512) {
