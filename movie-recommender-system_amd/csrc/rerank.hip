@@ -142,6 +142,74 @@ __device__ __forceinline__ bool ranks_before(double sa, int32_t ia, double sb, i
 }
 
 
+// the value lane (l ^ STRIDE) holds, without LDS: DPP quad permutes (1, 2) and row rotations (4: both directions + a select,
+// 8), v_permlane16_swap / v_permlane32_swap (gfx950) for 16 / 32 — ds_bpermute is an LDS round trip per dword
+template <int STRIDE>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v, int lane) {
+    typedef __attribute__((ext_vector_type(2))) unsigned int u2v;
+    if constexpr (STRIDE == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);        // quad_perm:[1,0,3,2]
+    else if constexpr (STRIDE == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm:[2,3,0,1]
+    else if constexpr (STRIDE == 4) {
+        const uint32_t below = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, false);  // row_ror:4: from lane l - 4
+        const uint32_t above = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x12C, 0xF, 0xF, false);  // row_ror:12: from lane l + 4
+        return (lane & 4) ? below : above;
+    } else if constexpr (STRIDE == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false);  // row_ror:8
+    else if constexpr (STRIDE == 16) {
+        const u2v r = __builtin_amdgcn_permlane16_swap(v, v, false, false);  // x: rows 0 0 2 2, y: rows 1 1 3 3
+        return (lane & 16) ? r.x : r.y;
+    } else {
+        static_assert(STRIDE == 32, "lane_xor: stride");
+        const u2v r = __builtin_amdgcn_permlane32_swap(v, v, false, false);  // x: lower half twice, y: upper half twice
+        return (lane & 32) ? r.x : r.y;
+    }
+}
+template <int STRIDE>
+__device__ __forceinline__ double lane_xor_f64(double v, int lane) {
+    const uint32_t lo = lane_xor<STRIDE>((uint32_t)__double2loint(v), lane), hi = lane_xor<STRIDE>((uint32_t)__double2hiint(v), lane);
+    return __hiloint2double((int)hi, (int)lo);
+}
+
+// the 512-element bitonic network of k_rerank<512> with one element per thread of a 512-thread workgroup held in registers
+// (see the call); asim / aidx: the elements (in: any order, out: best first), bsim / bidx: a second exchange buffer
+template <int SIZE, int STRIDE>
+__device__ __forceinline__ void sort512_stage(double& sv, int32_t& iv, int32_t e, double* asim, int32_t* aidx, double* bsim, int32_t* bidx) {
+    double sp;
+    int32_t ip;
+    if constexpr (STRIDE >= 64) {
+        // exchanges in network order: (128, 64) (256, 128) (256, 64) (512, 256) (512, 128) (512, 64) -> buffers a b a b a b
+        constexpr int nth = (SIZE == 128 ? 0 : SIZE == 256 ? 1 : 3) + (SIZE / 2 == STRIDE ? 0 : SIZE / 4 == STRIDE ? 1 : 2);
+        double* xs = (nth & 1) ? bsim : asim;
+        int32_t* xi = (nth & 1) ? bidx : aidx;
+        xs[e] = sv;
+        xi[e] = iv;
+        __syncthreads();
+        sp = xs[e ^ STRIDE];
+        ip = xi[e ^ STRIDE];
+    } else {
+        sp = lane_xor_f64<STRIDE>(sv, e & 63);
+        ip = (int32_t)lane_xor<STRIDE>((uint32_t)iv, e & 63);
+    }
+    const bool is_lo = (e & STRIDE) == 0, up = (e & SIZE) == 0;
+    const bool a_first = is_lo ? ranks_before(sv, iv, sp, ip) : ranks_before(sp, ip, sv, iv);
+    if (a_first != up) { sv = sp; iv = ip; }
+}
+template <int SIZE, int STRIDE>
+__device__ __forceinline__ void sort512_from(double& sv, int32_t& iv, int32_t e, double* asim, int32_t* aidx, double* bsim, int32_t* bidx) {
+    sort512_stage<SIZE, STRIDE>(sv, iv, e, asim, aidx, bsim, bidx);
+    if constexpr (STRIDE > 1) sort512_from<SIZE, STRIDE / 2>(sv, iv, e, asim, aidx, bsim, bidx);
+    else if constexpr (SIZE < 512) sort512_from<SIZE * 2, SIZE>(sv, iv, e, asim, aidx, bsim, bidx);
+}
+__device__ __attribute__((noinline)) void sort512_in_registers(double* asim, int32_t* aidx, double* bsim, int32_t* bidx) {
+    const int32_t e = threadIdx.x;
+    double sv = asim[e];
+    int32_t iv = aidx[e];
+    sort512_from<2, 1>(sv, iv, e, asim, aidx, bsim, bidx);
+    // (the sixth and last exchange went through the second buffer: nobody reads the first any more)
+    asim[e] = sv;
+    aidx[e] = iv;
+    __syncthreads();
+}
+
 // ---- K6b kernel ----------------------------------------------------------------------------------
 // One workgroup per panel row u.  u's item set lives in LDS as a BITMAP over the dense item index
 // plus per-word prefix popcounts, so "does u rate item c, and where" costs one LDS read (two more on a
@@ -450,31 +518,42 @@ __global__ void __launch_bounds__(TPB, RerankPlan<TILE>::WAVES_PER_EU) k_rerank(
             }
         }
         RPH(1);  // exact similarities (this wave)
-        for (int32_t c = take + threadIdx.x; c < m - best; c += TPB) {
+        // TILE = 512: one element per thread, the whole 512-element network (45 stages) with the element in REGISTERS — the 39
+        // stages whose partner sits in the same wave exchange through DPP / v_permlane*_swap, the 6 with strides 64 / 128 / 256 through
+        // LDS (two buffers in turn — the shortlist arrays and the idle product buffers — so that one barrier per stage is
+        // enough).  The all-LDS network below spent ~350 cycles per stage on LDS round trips with half of the threads idle
+        // (15 % of the kernel by its phase counters).
+        constexpr bool REG_SORT = TILE == 512 && TPB == 512 && (TPB / 64) * WBUF * 8 >= TILE * 12;
+        const int32_t m_pad = REG_SORT ? TILE : m;
+        for (int32_t c = take + threadIdx.x; c < m_pad - best; c += TPB) {
             ssim[best + c] = -INFINITY;
             sidx[best + c] = 0x7fffffff;
         }
         __syncthreads();
         RPH(2);  // wait for the other waves
-        for (int32_t size = 2; size <= m; size <<= 1) {
-            for (int32_t stride = size >> 1; stride > 0; stride >>= 1) {
-                for (int32_t t = threadIdx.x; t < (m >> 1); t += TPB) {
-                    int32_t lo = 2 * t - (t & (stride - 1));
-                    int32_t hi = lo + stride;
-                    bool up = ((lo & size) == 0);  // this sub-sequence ends "best first"
-                    double sa = ssim[lo], sb = ssim[hi];
-                    int32_t ia = sidx[lo], ib = sidx[hi];
-                    bool a_first = ranks_before(sa, ia, sb, ib);
-                    if (a_first != up) {
-                        ssim[lo] = sb; ssim[hi] = sa;
-                        sidx[lo] = ib; sidx[hi] = ia;
+        if constexpr (REG_SORT) {
+            sort512_in_registers(ssim, sidx, wbuf, reinterpret_cast<int32_t*>(wbuf + TILE));
+        } else {
+            for (int32_t size = 2; size <= m; size <<= 1) {
+                for (int32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                    for (int32_t t = threadIdx.x; t < (m >> 1); t += TPB) {
+                        int32_t lo = 2 * t - (t & (stride - 1));
+                        int32_t hi = lo + stride;
+                        bool up = ((lo & size) == 0);  // this sub-sequence ends "best first"
+                        double sa = ssim[lo], sb = ssim[hi];
+                        int32_t ia = sidx[lo], ib = sidx[hi];
+                        bool a_first = ranks_before(sa, ia, sb, ib);
+                        if (a_first != up) {
+                            ssim[lo] = sb; ssim[hi] = sa;
+                            sidx[lo] = ib; sidx[hi] = ia;
+                        }
                     }
+                    // a stage with stride <= 64 only moves data inside the 128-element blocks a wave owns (64 consecutive
+                    // pairs), so consecutive such stages need no workgroup barrier between them: 6 instead of 45 for m = 512
+                    const int32_t next_stride = stride > 1 ? (stride >> 1) : (((size << 1) <= m) ? size : 0);
+                    if (stride > 64 || next_stride > 64 || next_stride == 0) __syncthreads();
+                    else wave_sync();
                 }
-                // a stage with stride <= 64 only moves data inside the 128-element blocks a wave owns (64 consecutive
-                // pairs), so consecutive such stages need no workgroup barrier between them: 6 instead of 45 for m = 512
-                const int32_t next_stride = stride > 1 ? (stride >> 1) : (((size << 1) <= m) ? size : 0);
-                if (stride > 64 || next_stride > 64 || next_stride == 0) __syncthreads();
-                else wave_sync();
             }
         }
         best = min(kk, best + take);
