@@ -500,30 +500,30 @@ __global__ void __launch_bounds__(WAVES * 64) k_predict_knn_items(PredArgs A, in
         if (any) {
             const unsigned long long* gb = A.item_bits + (int64_t)item * ibw;
             const uint32_t* gr = A.item_rank + (int64_t)item * ibw;
-            // every load of a batch is requested before the first is used (six bitmap words and three rank words per thread
-            // and batch: two batches at the ml-25m shape).  One word per trip of a plain loop paid ten dependent global
-            // latencies per run — a third of the kernel's time by its phase counters (scripts/predict_phase_profile.sh)
-            constexpr int NT = WAVES * 64;
-            for (int w0 = 0; w0 < 2 * ibw2; w0 += 6 * NT) {
-                unsigned long long bv[6];
-                uint32_t rv[3];
+            // every load of a batch is requested before the first is used (twelve bitmap words and six rank words per thread
+            // and batch: ONE batch up to 196 608 users).  One word per trip of a plain loop paid ten dependent global
+            // latencies per run — a third of the kernel's time by its phase counters (scripts/phase_profile.sh)
+            constexpr int NT = WAVES * 64, NB = 12;
+            for (int w0 = 0; w0 < 2 * ibw2; w0 += NB * NT) {
+                unsigned long long bv[NB];
+                uint32_t rv[NB / 2];
 #pragma unroll
-                for (int q = 0; q < 6; ++q) {
+                for (int q = 0; q < NB; ++q) {
                     const int w = w0 + q * NT + (int)threadIdx.x;
                     bv[q] = w < ibw ? gb[w] : 0ull;
                 }
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
+                for (int q = 0; q < NB / 2; ++q) {
                     const int j = (w0 >> 1) + q * NT + (int)threadIdx.x;
                     rv[q] = 2 * j < ibw ? gr[2 * j] : 0u;
                 }
 #pragma unroll
-                for (int q = 0; q < 6; ++q) {
+                for (int q = 0; q < NB; ++q) {
                     const int w = w0 + q * NT + (int)threadIdx.x;
                     if (w < 2 * ibw2) bits[w] = bv[q];
                 }
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
+                for (int q = 0; q < NB / 2; ++q) {
                     const int j = (w0 >> 1) + q * NT + (int)threadIdx.x;
                     if (j < ibw2) rnk[j] = rv[q];
                 }
