@@ -1,16 +1,15 @@
 # usage (GPU box, repo root): bash scripts/round_final.sh <tag>
-# The round's closing measurement set in ONE call: phase profiles of k_rerank / k_tail_select (profiling builds), then the default
-# build's bench + rocprofv3 kernel summary + PMC passes (profile_round.sh), the 8-shard rehearsal and a fuzz parity sweep.
+# The round's closing measurement set in ONE call: phase profiles of k_tail_select / k_rerank / k_predict_knn_items (profiling
+# builds), then the default build's bench + rocprofv3 kernel summary + PMC passes (profile_round.sh), the 8-shard rehearsal and
+# a fuzz parity sweep.
 TAG=${1:-rXX}
 O=gpurun_out/$TAG
 mkdir -p $O
-KNNCF_EXTRA_HIPCC_FLAGS=-DKNNCF_RERANK_PROFILE python -c "
-import importlib
-importlib.import_module('movie-recommender-system_amd.build').build(force=True)" || exit 1
-timeout -k 10 300 python bench.py --no-cpu-baseline --no-bf16-leg --steps 1 --warmup 1 > $O/rerank_phases.json 2> $O/rerank_phases.err
-grep "rerank profile" $O/rerank_phases.err | tail -3
-bash scripts/select_phase_profile.sh $TAG > $O/select_phases.txt 2>&1
-tail -14 $O/select_phases.txt
+for K in SELECT RERANK PREDICT; do
+  bash scripts/phase_profile.sh ${TAG}_phase_$K KNNCF_${K}_PROFILE > $O/phases_$K.txt 2>&1
+  grep -A11 -i "profile\]" gpurun_out/${TAG}_phase_$K/phases.err | tail -12 >> $O/phases_$K.txt
+  tail -12 $O/phases_$K.txt
+done
 python -c "
 import importlib
 importlib.import_module('movie-recommender-system_amd.build').build(force=True)" || exit 1
