@@ -552,7 +552,7 @@ void build_neighbors(knncf_handle* h, int32_t count) {
                           h->sel.row_entries.p, verify, sc, n_heavy, slices, &h->slices);
         }
         if (!overlap) KN_HIP(hipEventRecord(h->ev_consumed[slot], sc));
-        KN_HIP(hipMemcpyAsync(h->pinned_cnt + rb, h->sel.cand_cnt.p, rows * sizeof(int32_t), hipMemcpyDeviceToHost, sc));
+        if (per_block_redo) KN_HIP(hipMemcpyAsync(h->pinned_cnt + rb, h->sel.cand_cnt.p, rows * sizeof(int32_t), hipMemcpyDeviceToHost, sc));
         if (per_block_redo) {
             // several row blocks (syn-1M, capped workspaces): the block's panel slot is about to be recycled, so rows whose
             // anticipated thresholds overshot are re-selected NOW if they are many (one host round trip per block: the
@@ -567,8 +567,38 @@ void build_neighbors(knncf_handle* h, int32_t count) {
             if (overlap) KN_HIP(hipEventRecord(h->ev_consumed[slot], sc));  // (only now may the producer recycle S[slot])
         }
     }
+    // One-launch builds (whole-matrix, or one row block): the device has summed what the host needs to know about the rows
+    // (stats[2] shortlist lengths, stats[3] rows to rebuild: k_sum_row_entries), so the id-ordered copy of the lists is queued
+    // at once and ONE four-word read-back ends the build; the per-row counts are fetched only if a row has to be rebuilt.
+    // (Walking 162 541 counts on the host between the re-rank and the prediction left the GPU idle for 0.25 ms per step.)
+    const bool summary = !per_block_redo;
+    unsigned long long four[4] = {0, 0, 0, 0};
+    if (summary) {
+        {
+            Stage s(h, &h->tm.rerank_ms, sc);
+            launch_sort_neighbors(nt, count, h->build_list.p, sc);
+        }
+        KN_HIP(hipMemcpyAsync(four, h->sel.stats.p, sizeof(four), hipMemcpyDeviceToHost, sc));
+    }
     KN_HIP(hipStreamSynchronize(sc));
     KN_HIP(hipStreamSynchronize(sp));
+    auto take_stats = [&](const unsigned long long* w) {
+        h->tm.rerank_row_bytes += 12.0 * (double)w[1];
+        if (verify && w[0] != 0) {
+            double shifted;
+            memcpy(&shifted, &w[0], sizeof(double));
+            h->tm.max_bound_violation = std::max(h->tm.max_bound_violation, shifted - 4.0);
+        }
+    };
+    if (summary && four[3] == 0) {  // every list is final
+        h->tm.shortlist_total += (double)four[2];
+        take_stats(four);
+        return;
+    }
+    if (summary) {
+        KN_HIP(hipMemcpyAsync(h->pinned_cnt, h->sel.cand_cnt.p, (size_t)count * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        KN_HIP(hipStreamSynchronize(st));
+    }
     // select.hip anticipates its emission thresholds and marks a row whose guess overshot (like one whose stores overflowed)
     // for the exact fallback below — a 7-sigma event per row when the dense user order is a pseudo-random column sample,
     // which HashSet ranks of the raw ids are.  Should a data set defeat that (many rows marked), the marked rows are not sent
@@ -576,7 +606,7 @@ void build_neighbors(knncf_handle* h, int32_t count) {
     // plain thresholds (redo_marked): the anticipation can then cost at most one extra pass.  Whole-matrix builds and
     // one-block row-block builds do it here (the similarity panel is still there); builds of several row blocks did it per
     // block, before the block's panel slot was recycled (above).
-    if (use_sym || n_blocks == 1) {
+    if (summary) {
         std::vector<int32_t> marked;
         for (int64_t r = 0; r < count; ++r)
             if (h->pinned_cnt[r] > cap) marked.push_back((int32_t)r);
@@ -604,19 +634,13 @@ void build_neighbors(knncf_handle* h, int32_t count) {
     }
     {
         Stage s(h, &h->tm.rerank_ms);
-        launch_sort_neighbors(nt, count, h->build_list.p, st);
+        launch_sort_neighbors(nt, count, h->build_list.p, st);  // (again, where it ran ahead: some lists were rebuilt)
     }
     {
         unsigned long long two[2] = {0, 0};
         KN_HIP(hipMemcpyAsync(two, h->sel.stats.p, sizeof(two), hipMemcpyDeviceToHost, st));
         KN_HIP(hipStreamSynchronize(st));
-        h->tm.rerank_row_bytes += 12.0 * (double)two[1];
-        const unsigned long long bits = two[0];
-        if (verify && bits != 0) {
-            double shifted;
-            memcpy(&shifted, &bits, sizeof(double));
-            h->tm.max_bound_violation = std::max(h->tm.max_bound_violation, shifted - 4.0);
-        }
+        take_stats(two);
     }
 }
 

@@ -600,17 +600,31 @@ static void rerank_profile_dump() {
 }
 #endif
 
-// stats[1] += sum of the per-row candidate-entry counts (the kernel's algorithmic traffic / 12 B): one atomic per block
-__global__ void __launch_bounds__(1024) k_sum_row_entries(int32_t n_rows, const uint32_t* __restrict__ row_entries, unsigned long long* __restrict__ total) {
-    __shared__ unsigned long long part;
-    if (threadIdx.x == 0) part = 0;
+// stats[1] += sum of the per-row candidate-entry counts (the kernel's algorithmic traffic / 12 B), stats[2] += the shortlist
+// lengths min(cand_cnt, cap), stats[3] += the rows whose shortlist overflowed or whose anticipated threshold overshot
+// (cand_cnt > cap: the rows api.cpp rebuilds) — one atomic per block and word, so that the host reads four words instead of
+// walking 162 541 counts between the re-rank and the prediction
+__global__ void __launch_bounds__(1024) k_sum_row_entries(int32_t n_rows, const uint32_t* __restrict__ row_entries, const int32_t* __restrict__ cand_cnt,
+                                                          int32_t cap, unsigned long long* __restrict__ total) {
+    __shared__ unsigned long long part[3];
+    if (threadIdx.x < 3) part[threadIdx.x] = 0;
     __syncthreads();
     const int32_t r = blockIdx.x * 1024 + threadIdx.x;
     unsigned long long v = r < n_rows ? row_entries[r] : 0ull;
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&part, v);
+    const int32_t c = r < n_rows ? cand_cnt[r] : 0;
+    unsigned long long len = (unsigned long long)min(c, cap), over = c > cap ? 1ull : 0ull;
+    for (int o = 32; o > 0; o >>= 1) {
+        v += __shfl_xor(v, o);
+        len += __shfl_xor(len, o);
+        over += __shfl_xor(over, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (v) atomicAdd(&part[0], v);
+        if (len) atomicAdd(&part[1], len);
+        if (over) atomicAdd(&part[2], over);
+    }
     __syncthreads();
-    if (threadIdx.x == 0 && part) atomicAdd(total, part);
+    if (threadIdx.x < 3 && part[threadIdx.x]) atomicAdd(total + threadIdx.x, part[threadIdx.x]);
 }
 
 template <int TILE, bool JAC>
@@ -627,7 +641,7 @@ static void launch_rerank_tile(const Rows& R, const Train& tr, NeighborTable& nt
     const int32_t grid = n_rows + sl.n_heavy * (sl.P - 1);
     k_rerank<TILE, JAC><<<grid, TPB, smem, st>>>(R, nt.seq.p, n_rows, d_row_user, cap, cand_idx, cand_approx, cand_cnt, nt.kcap,
                                             nt.kcap, nt.idx.p, nt.sim.p, nt.cnt.p, cand_eps, d_stats, d_row_entries, words, sl);
-    k_sum_row_entries<<<(unsigned)ceil_div(n_rows, 1024), 1024, 0, st>>>(n_rows, d_row_entries, reinterpret_cast<unsigned long long*>(d_stats) + 1);
+    k_sum_row_entries<<<(unsigned)ceil_div(n_rows, 1024), 1024, 0, st>>>(n_rows, d_row_entries, cand_cnt, cap, reinterpret_cast<unsigned long long*>(d_stats) + 1);
     KN_HIP(hipGetLastError());
 #ifdef KNNCF_RERANK_PROFILE
     KN_HIP(hipStreamSynchronize(st));
