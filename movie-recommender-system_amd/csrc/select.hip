@@ -801,31 +801,52 @@ __global__ void __launch_bounds__(TPB, WAVES_PER_EU) k_tail_select(const ST* __r
         if (threadIdx.x == 0) cand_cnt[r] = 0x7fffffff;
         return;
     }
-    count_new_groups(s_thr);
+    // The stored groups are read ONCE, every load requested before the first is used: a thread keeps its groups of the first
+    // FB trips (FB * TPB = 2048 groups; a row of the ml-25m shape stores ~1000) in registers from the histogram pass to the
+    // extraction.  (Two passes of one group per thread and trip — the histogram's and the extraction's — each paid a global
+    // latency per trip: 13 % of the kernel by its phase counters.)
+    constexpr int FB = 4;
+    const uint32_t G = s_count;
+    float4 fxa[FB], fxb[FB];
+    int32_t fv0[FB];
+#pragma unroll
+    for (int q = 0; q < FB; ++q) {
+        const uint32_t g = (uint32_t)q * TPB + threadIdx.x;
+        fxa[q] = fxb[q] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        fv0[q] = 0;
+        if (g < G) {
+            fxa[q] = g_x[2 * g];
+            fxb[q] = g_x[2 * g + 1];
+            fv0[q] = g_v0[g];
+        }
+    }
+    {
+        const float floor = s_thr;
+#pragma unroll
+        for (int q = 0; q < FB; ++q) {
+            const uint32_t g = (uint32_t)q * TPB + threadIdx.x;
+            if (g >= counted && g < G) {
+                const float x8[8] = {fxa[q].x, fxa[q].y, fxa[q].z, fxa[q].w, fxb[q].x, fxb[q].y, fxb[q].z, fxb[q].w};
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (x8[i] >= floor && x8[i] > -INFINITY) atomicAdd(&hist[sim_bin(x8[i])], 1u);
+            }
+        }
+        counted = max(counted, min(G, (uint32_t)FB * TPB));
+        count_new_groups(floor);  // (the groups beyond the registers, if any; ends with the barrier)
+    }
     block_threshold(hist, wtot, &s_thr, &s_bin, kk, eps);  // final: every value that can matter is in the histogram
+    PH(10);  // the final threshold (the groups stored since the last refresh into the histogram)
     if (s_bin < bin_used) {  // an anticipated threshold overshot (see rank_after): the store may lack a neighbour -> exact fallback
         if (threadIdx.x == 0) cand_cnt[r] = 0x7fffffff;
         return;
     }
     {
         const float thr = s_thr;
-        const uint32_t G = s_count;
         uint32_t& s_out = wtot[TPB / 64 + 3];
         if (threadIdx.x == 0) s_out = 0;
         __syncthreads();
-        for (uint32_t g0 = 0; g0 < G; g0 += TPB) {
-            const uint32_t g = g0 + threadIdx.x;
-            float x8[8];
-            int32_t v0 = 0;
-            uint32_t m = 0;
-            if (g < G) {
-                v0 = g_v0[g];
-                const float4 a = g_x[2 * g], b4 = g_x[2 * g + 1];
-                x8[0] = a.x; x8[1] = a.y; x8[2] = a.z; x8[3] = a.w; x8[4] = b4.x; x8[5] = b4.y; x8[6] = b4.z; x8[7] = b4.w;
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    if (x8[i] >= thr && x8[i] > -INFINITY) m |= 1u << i;
-            }
+        auto emit = [&](uint32_t m, int32_t v0, const float* x8) {  // (all lanes of the wave call it together)
             const uint32_t cnt = __popc(m);
             const uint32_t incl = wave_incl_scan(cnt);
             const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
@@ -845,10 +866,36 @@ __global__ void __launch_bounds__(TPB, WAVES_PER_EU) k_tail_select(const ST* __r
                     }
                 }
             }
+        };
+#pragma unroll
+        for (int q = 0; q < FB; ++q) {
+            if ((uint32_t)q * TPB >= G) break;  // (block-uniform)
+            const float x8[8] = {fxa[q].x, fxa[q].y, fxa[q].z, fxa[q].w, fxb[q].x, fxb[q].y, fxb[q].z, fxb[q].w};
+            uint32_t m = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (x8[i] >= thr && x8[i] > -INFINITY) m |= 1u << i;  // (absent groups hold -inf)
+            emit(m, fv0[q], x8);
+        }
+        for (uint32_t g0 = (uint32_t)FB * TPB; g0 < G; g0 += TPB) {
+            const uint32_t g = g0 + threadIdx.x;
+            float x8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            int32_t v0 = 0;
+            uint32_t m = 0;
+            if (g < G) {
+                v0 = g_v0[g];
+                const float4 a = g_x[2 * g], b4 = g_x[2 * g + 1];
+                x8[0] = a.x; x8[1] = a.y; x8[2] = a.z; x8[3] = a.w; x8[4] = b4.x; x8[5] = b4.y; x8[6] = b4.z; x8[7] = b4.w;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (x8[i] >= thr && x8[i] > -INFINITY) m |= 1u << i;
+            }
+            emit(m, v0, x8);
         }
         __syncthreads();
         if (threadIdx.x == 0) cand_cnt[r] = (int32_t)min(s_out, (uint32_t)0x7fffffff);  // (> cap: overflow, exact fallback)
     }
+    PH(11);  // the shortlist out of the stored groups
     return;
 }
 
@@ -859,7 +906,7 @@ void select_profile_dump() {
     unsigned long long tot = 0;
     for (int i = 0; i < 16; ++i) tot += h[i];
     fprintf(stderr, "[select profile] cycles per phase (thread 0 of every block), total %.3e\n", (double)tot);
-    for (int i = 0; i <= 10; ++i) fprintf(stderr, "  phase %2d: %6.2f %%\n", i, 100.0 * (double)h[i] / (double)tot);
+    for (int i = 0; i <= 11; ++i) fprintf(stderr, "  phase %2d: %6.2f %%\n", i, 100.0 * (double)h[i] / (double)tot);
     memset(h, 0, sizeof(h));
     hipMemcpyToSymbol(HIP_SYMBOL(g_phase), h, sizeof(h));
 }
