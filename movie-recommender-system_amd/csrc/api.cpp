@@ -24,7 +24,6 @@ void launch_fallback_write(int32_t user, int32_t take, int32_t kcap, const uint3
                            const double* d_exact, int32_t* nbr_idx, double* nbr_sim, int32_t* nbr_cnt,
                            hipStream_t st);
 void launch_jaccard_pair(const Train& tr, int32_t u, int32_t v, double* d_out, hipStream_t st);
-void launch_sort_neighbors(NeighborTable& nt, int32_t n_rows, const int32_t* d_row_user, hipStream_t st);
 }  // namespace knncf
 
 struct StageTimer {
@@ -210,8 +209,7 @@ void reset_neighbors(knncf_handle* h) {
     size_t cells = (size_t)tr.U * (size_t)std::max(nt.kcap, 1);
     nt.idx.ensure(cells);
     nt.sim.ensure(cells);
-    nt.uidx.ensure(cells);
-    nt.usim.ensure(cells);
+    nt.by_id_valid = false;  // (uidx / usim: made by launch_predict when a kernel wants them)
     nt.cnt.ensure(tr.U);
     nt.seq.ensure(tr.U);
     KN_HIP(hipMemsetAsync(nt.cnt.p, 0, tr.U * sizeof(int32_t), h->stream));
@@ -568,18 +566,12 @@ void build_neighbors(knncf_handle* h, int32_t count) {
         }
     }
     // One-launch builds (whole-matrix, or one row block): the device has summed what the host needs to know about the rows
-    // (stats[2] shortlist lengths, stats[3] rows to rebuild: k_sum_row_entries), so the id-ordered copy of the lists is queued
-    // at once and ONE four-word read-back ends the build; the per-row counts are fetched only if a row has to be rebuilt.
+    // (stats[2] shortlist lengths, stats[3] rows to rebuild: k_sum_row_entries), so ONE four-word read-back ends the build; the per-row counts are fetched only if a row has to be rebuilt.
     // (Walking 162 541 counts on the host between the re-rank and the prediction left the GPU idle for 0.25 ms per step.)
     const bool summary = !per_block_redo;
     unsigned long long four[4] = {0, 0, 0, 0};
-    if (summary) {
-        {
-            Stage s(h, &h->tm.rerank_ms, sc);
-            launch_sort_neighbors(nt, count, h->build_list.p, sc);
-        }
-        KN_HIP(hipMemcpyAsync(four, h->sel.stats.p, sizeof(four), hipMemcpyDeviceToHost, sc));
-    }
+    nt.by_id_valid = false;  // (the id-sorted copies are made by launch_predict when a kernel wants them)
+    if (summary) KN_HIP(hipMemcpyAsync(four, h->sel.stats.p, sizeof(four), hipMemcpyDeviceToHost, sc));
     KN_HIP(hipStreamSynchronize(sc));
     KN_HIP(hipStreamSynchronize(sp));
     auto take_stats = [&](const unsigned long long* w) {
@@ -631,10 +623,6 @@ void build_neighbors(knncf_handle* h, int32_t count) {
                                   nt.cnt.p, st);
             h->tm.fallback_rows += 1;
         }
-    }
-    {
-        Stage s(h, &h->tm.rerank_ms);
-        launch_sort_neighbors(nt, count, h->build_list.p, st);  // (again, where it ran ahead: some lists were rebuilt)
     }
     {
         unsigned long long two[2] = {0, 0};
@@ -692,6 +680,7 @@ void ensure_personalized_table(knncf_handle* h) {
     pt.usim.ensure(cells);
     pt.cnt.ensure(tr.U);
     launch_full_rows(tr, h->cfg.similarity == KNNCF_SIM_JACCARD, pt.uidx.p, pt.usim.p, pt.cnt.p, h->stream);
+    pt.by_id_valid = true;
     h->pt_ready = true;
 }
 
@@ -715,7 +704,7 @@ void run_predict(knncf_handle* h, int predictor, const int32_t* d_users, const i
     if (n == 0) return;
     KN_REQUIRE(d_users && d_items, KNNCF_E_INVALID, "null test arrays");
     int kind = predictor;
-    const NeighborTable* table = &h->nt;
+    NeighborTable* table = &h->nt;
     if (predictor == KNNCF_PRED_PERSONALIZED) {
         if (h->cfg.similarity == KNNCF_SIM_ONE) {
             kind = KNNCF_PRED_BASELINE_RDD;  // num/den = file-order mean of the item's deviations (see predict.hip)
@@ -935,15 +924,7 @@ void do_neighbors_load(knncf_handle* h, const char* path) {
     KN_HIP(hipMemcpyAsync(nt.seq.p, seq.data(), seq.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
     KN_HIP(hipMemcpyAsync(nt.idx.p, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     KN_HIP(hipMemcpyAsync(nt.sim.p, sim.data(), sim.size() * sizeof(double), hipMemcpyHostToDevice, st));
-    // the id-sorted copies the prediction streams: for every user that has a list
-    std::vector<int32_t> built;
-    for (int32_t u = 0; u < tr.U; ++u)
-        if (seq[u] >= 0) built.push_back(u);
-    if (!built.empty() && nt.kcap > 0) {
-        h->build_list.ensure(tr.U);
-        KN_HIP(hipMemcpyAsync(h->build_list.p, built.data(), built.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-        launch_sort_neighbors(nt, (int32_t)built.size(), h->build_list.p, st);
-    }
+    nt.by_id_valid = false;
     KN_HIP(hipStreamSynchronize(st));
     h->epoch = std::max<int64_t>(hd.epoch, 1);
 }

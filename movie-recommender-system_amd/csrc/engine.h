@@ -162,8 +162,9 @@ struct NeighborTable {
     int32_t kcap = 0;  // min(k, U-1): stored neighbours per user
     DArr<int32_t> idx;   // [U * kcap] dense neighbour ids, reference order
     DArr<double> sim;    // [U * kcap]
-    DArr<int32_t> uidx;  // [U * kcap] the same neighbours sorted by dense id (prediction probes)
-    DArr<double> usim;   // [U * kcap]
+    DArr<int32_t> uidx;  // [U * kcap] the same neighbours sorted by dense id: built on demand (launch_predict) for the prediction
+    DArr<double> usim;   // [U * kcap]   kernels that probe in global memory; the item-grouped kernel streams idx / sim as they are
+    bool by_id_valid = false;  // uidx / usim hold the current lists
     DArr<int32_t> cnt;   // [U] 0 until built
     DArr<int64_t> seq;   // [U] build sequence number (memo history); -1 = not built
 };
@@ -236,7 +237,9 @@ void launch_exact_pair(const Train& tr, int32_t u, int32_t v, double* d_out, hip
 // ---- predict.hip: K7-K9 ----------------------------------------------------------------
 // per test row: prediction of `predictor`; rows whose user is outside [own_lo, own_hi) are
 // skipped (unknown users belong to shard 0).  d_abs_err[t] = |r - p| or 0 for skipped rows.
-void launch_predict(const Train& tr, const NeighborTable* nt, int predictor, int64_t n,
+// id-sorted copies of the lists of the given users (d_row_user == nullptr: of every user)
+void launch_sort_neighbors(NeighborTable& nt, int32_t n_rows, const int32_t* d_row_user, hipStream_t st);
+void launch_predict(const Train& tr, NeighborTable* nt, int predictor, int64_t n,
                     const int32_t* d_du, const int32_t* d_di, const double* d_ratings,
                     const uint32_t* d_order, bool order_by_item, double* d_pred, double* d_abs_err, uint8_t* d_owned,
                     bool unknown_users_owned, hipStream_t st);

@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(256) k_sort_neighbors_by_id(int32_t n_rows, co
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int32_t r = blockIdx.x;
     if (r >= n_rows) return;
-    const int32_t u = row_user[r];
+    const int32_t u = row_user ? row_user[r] : r;
     const int32_t cnt = nbr_cnt[u];
     int32_t m = 128;  // (whole blocks of 128: the wave-local stages assume them)
     while (m < cnt) m <<= 1;
@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(256) k_rank_neighbors_by_id(int32_t n_rows, co
     uint32_t* base_of = bits + 2 * words;                // [words] ids of the row below word w
     const int32_t r = blockIdx.x;
     if (r >= n_rows) return;
-    const int32_t u = row_user[r];
+    const int32_t u = row_user ? row_user[r] : r;
     const int32_t cnt = nbr_cnt[u];
     const int64_t base = (int64_t)u * kcap;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -232,6 +232,9 @@ __global__ void __launch_bounds__(256) k_rank_neighbors_by_id(int32_t n_rows, co
 
 void launch_sort_neighbors(NeighborTable& nt, int32_t n_rows, const int32_t* d_row_user, hipStream_t st) {
     if (n_rows <= 0 || nt.kcap <= 0) return;
+    const size_t cells = nt.cnt.n * (size_t)nt.kcap;
+    nt.uidx.ensure(cells);
+    nt.usim.ensure(cells);
     {
         const int64_t U = (int64_t)nt.cnt.n;  // (one count per user)
         const int32_t words = (int32_t)ceil_div(U, 64);

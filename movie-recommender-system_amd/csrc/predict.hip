@@ -785,7 +785,7 @@ __global__ void k_predict_simple(PredArgs A, int kind, int64_t n, const int32_t*
     owned[t] = 1;
 }
 
-void launch_predict(const Train& tr, const NeighborTable* nt, int predictor, int64_t n, const int32_t* d_du,
+void launch_predict(const Train& tr, NeighborTable* nt, int predictor, int64_t n, const int32_t* d_du,
                     const int32_t* d_di, const double* d_ratings, const uint32_t* d_order, bool order_by_item,
                     double* d_pred, double* d_abs_err, uint8_t* d_owned, bool unknown_users_owned, hipStream_t st) {
     if (n <= 0) return;
@@ -796,11 +796,25 @@ void launch_predict(const Train& tr, const NeighborTable* nt, int predictor, int
     A.own_lo = tr.own_lo; A.own_hi = tr.own_hi;
     if (predictor == KNNCF_PRED_KNN) {
         KN_REQUIRE(nt != nullptr, KNNCF_E_STATE, "predict: neighbour table missing");
-        A.nbr_uidx = nt->uidx.p; A.nbr_usim = nt->usim.p; A.nbr_cnt = nt->cnt.p; A.kcap = nt->kcap;
+        A.nbr_cnt = nt->cnt.p; A.kcap = nt->kcap;
+        // The item-grouped kernel probes an LDS bitmap and orders its matches by file row: the order of a list does not
+        // matter to it, and it streams the lists as the re-rank left them (reference order).  The kernels that probe in global
+        // memory want neighbouring lanes on neighbouring ids (cache sectors): they take the id-sorted copies, made here on
+        // first need (0.7 ms per step at the ml-25m shape when it was part of every build).
+        const bool items_path = d_order && order_by_item && tr.ib_words > 0 && tr.ib_words * 12 <= 48 * 1024 && nt->kcap <= 512;
+        if (items_path && nt->idx.p != nullptr) {
+            A.nbr_uidx = nt->idx.p; A.nbr_usim = nt->sim.p;
+        } else {
+            if (!nt->by_id_valid) {
+                launch_sort_neighbors(*nt, (int32_t)nt->cnt.n, nullptr, st);
+                nt->by_id_valid = true;
+            }
+            A.nbr_uidx = nt->uidx.p; A.nbr_usim = nt->usim.p;
+        }
         A.i_ptr = tr.i_ptr.p; A.it_user = tr.it_user.p; A.it_dev = tr.it_dev.p; A.it_t = tr.it_t.p;
         A.ib_words = tr.ib_words; A.item_bits = reinterpret_cast<const unsigned long long*>(tr.item_bits.p); A.item_rank = tr.item_rank.p;
         const double bits_total = (double)tr.I * (double)tr.ib_words * 8.0;
-        if (d_order && order_by_item && tr.ib_words > 0 && tr.ib_words * 12 <= 48 * 1024 && nt->kcap <= 512) {
+        if (items_path) {
             A.n_bytes4 = (uint32_t)(tr.n * 4);
             const int trips = (nt->kcap + 63) / 64;
             const unsigned blocks = (unsigned)ceil_div(n, KNNCF_PRED_CHUNK);
