@@ -532,29 +532,40 @@ __global__ void __launch_bounds__(TPB, WAVES_PER_EU) k_tail_select(const ST* __r
 #define KN_TAIL_APPLY8(S)                                                                                          \
     KN_TAIL_APPLY(S "0", 0, 15) KN_TAIL_APPLY(S "1", 1, 14) KN_TAIL_APPLY(S "2", 2, 13) KN_TAIL_APPLY(S "3", 3, 12) \
     KN_TAIL_APPLY(S "4", 4, 11) KN_TAIL_APPLY(S "5", 5, 10) KN_TAIL_APPLY(S "6", 6, 9) KN_TAIL_APPLY(S "7", 7, 8)
+#define KN_TAIL_APPLY8_LAST(S) /* no younger group in flight behind this one */                                   \
+    KN_TAIL_APPLY(S "0", 0, 7) KN_TAIL_APPLY(S "1", 1, 6) KN_TAIL_APPLY(S "2", 2, 5) KN_TAIL_APPLY(S "3", 3, 4) \
+    KN_TAIL_APPLY(S "4", 4, 3) KN_TAIL_APPLY(S "5", 5, 2) KN_TAIL_APPLY(S "6", 6, 1) KN_TAIL_APPLY(S "7", 7, 0)
     // all groups of a window (n8 = its pieces rounded up to whole groups, 8 .. 64), software-pipelined two groups deep:
     // group g + 1's loads are issued before group g's atomics, into the other register set (A / B alternate, the loop is
-    // unrolled twice).  A next group is ALWAYS issued — past the window's end it re-reads the descriptors of lanes 0 .. 7
-    // (v_readlane takes the lane select modulo 64): mapped memory, never applied — so that the vmcnt counts are the same
-    // for every group; the final vmcnt(0) retires that last, unused group before the registers go back to the compiler.
+    // unrolled twice).  The LAST group of a window is applied without a look-ahead group behind it (its own code copy: the
+    // vmcnt immediates count 8 loads fewer).  Round 2 always issued a next group — past the window's end a dummy one, so that
+    // one set of immediates served every group — and waited for it at the end: a window of 9 .. 16 pieces (a wave's share of a
+    // tile is ~23 at the ml-25m shape) then cost two memory latencies instead of one.
     auto tail_window = [&](uint32_t n8) {
         uint32_t a0, a1, a2, a3, a4, a5, a6, a7, b0, b1, b2, b3, b4, b5, b6, b7, t, a, sq, sx, sj, sg;
         asm volatile(
             "s_mov_b32 %[sg], 0\n\t"
             KN_TAIL_ISSUE8("a", 0)
             "1:\n\t"
+            "s_add_u32 %[sj], %[sg], 8\n\t"
+            "s_cmp_ge_u32 %[sj], %[n8]\n\t"
+            "s_cbranch_scc1 3f\n\t"
             KN_TAIL_ISSUE8("b", 8)
             KN_TAIL_APPLY8("a")
             "s_add_u32 %[sg], %[sg], 8\n\t"
-            "s_cmp_ge_u32 %[sg], %[n8]\n\t"
-            "s_cbranch_scc1 2f\n\t"
+            "s_add_u32 %[sj], %[sg], 8\n\t"
+            "s_cmp_ge_u32 %[sj], %[n8]\n\t"
+            "s_cbranch_scc1 4f\n\t"
             KN_TAIL_ISSUE8("a", 8)
             KN_TAIL_APPLY8("b")
             "s_add_u32 %[sg], %[sg], 8\n\t"
-            "s_cmp_lt_u32 %[sg], %[n8]\n\t"
-            "s_cbranch_scc1 1b\n\t"
-            "2:\n\t"
-            "s_waitcnt vmcnt(0)\n\t"
+            "s_branch 1b\n\t"
+            "3:\n\t"
+            KN_TAIL_APPLY8_LAST("a")
+            "s_branch 5f\n\t"
+            "4:\n\t"
+            KN_TAIL_APPLY8_LAST("b")
+            "5:\n\t"
             : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [a4] "=&v"(a4), [a5] "=&v"(a5), [a6] "=&v"(a6),
               [a7] "=&v"(a7), [b0] "=&v"(b0), [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3), [b4] "=&v"(b4), [b5] "=&v"(b5),
               [b6] "=&v"(b6), [b7] "=&v"(b7), [t] "=&v"(t), [a] "=&v"(a), [sq] "=&s"(sq), [sx] "=&s"(sx), [sj] "=&s"(sj),
@@ -564,6 +575,7 @@ __global__ void __launch_bounds__(TPB, WAVES_PER_EU) k_tail_select(const ST* __r
     };
 #undef KN_TAIL_ISSUE8
 #undef KN_TAIL_APPLY8
+#undef KN_TAIL_APPLY8_LAST
 #undef KN_TAIL_ISSUE
 #undef KN_TAIL_APPLY
     auto drain = [&](bool) {
