@@ -37,7 +37,7 @@ def main():
                 lines = [l for l in open(p).read().splitlines() if "profile" in l or l.strip().startswith("phase")]
                 note = " — phase 1 of k_tail_select includes the wait for the profiling atomic issued at the barrier before it" if k == "SELECT" else ""
                 f.write(f"== {k}: scripts/phase_profile.sh, -DKNNCF_{k}_PROFILE (thread 0 of every workgroup; the counters slow the kernel{note}) ==\n")
-                f.write("\n".join(lines[-12:] if k == "SELECT" else lines[-1:]) + "\n")
+                f.write("\n".join(lines[-13:] if k == "SELECT" else lines[-1:]) + "\n")
     print("installed", rnd, "from", src)
 
 

@@ -7,7 +7,7 @@ O=gpurun_out/$TAG
 mkdir -p $O
 for K in SELECT RERANK PREDICT; do
   bash scripts/phase_profile.sh ${TAG}_phase_$K KNNCF_${K}_PROFILE > $O/phases_$K.txt 2>&1
-  grep -A11 -i "profile\]" gpurun_out/${TAG}_phase_$K/phases.err | tail -12 >> $O/phases_$K.txt
+  grep -A11 -i "profile\]" gpurun_out/${TAG}_phase_$K/phases.err | tail -14 >> $O/phases_$K.txt
   tail -12 $O/phases_$K.txt
 done
 python -c "
