@@ -307,13 +307,15 @@ def main():
                                   "unit": "TB/s", "definition": "panel bytes + 4 B per tail pair product (L2 / Infinity-Cache re-reads of the rater lists; NOT HBM bytes)"},
         }
         ts["binding"] = ("neither throughput roof of the line: the kernel alternates a panel scan (HBM: 53 GB per step at ~4.6 TB/s when run "
-                         "alone, 11.5 ms) with the tail drain, which is bound by the Infinity Cache — ~3e8 pieces x 256 B = 77 GB per step out of "
-                         "the 80 MB rater-list array (it cannot live in the 4 MB L2s) at ~7 TB/s of the ~8.6 TB/s measured for uniformly gathered "
-                         "tables of that size.  Evidence (DESIGN.md section 4, profiles/README.md): timing-only ablations of the round-2 build at "
-                         "H = 384 (26.7 ms kernel): no tail machinery 11.5 ms, + tail set-up and read-out 15.6, + the drain 26.7; round 3 cut the "
-                         "drain from 8 to 6 VALU per piece and its marginal rate did not move (4.2e-13 s per pair product before and after, head "
-                         "sweeps 256 .. 640): not instruction issue.  SQ pass of profiles/" + PMC_PROFILE + ": VALU issue and waiting fractions. "
-                         "HBM frac on compulsory bytes and the LDS-atomic frac are both reported")
+                         "alone, 11.5 ms) with the tail drain — ~3e8 pieces x 256 B = 77 GB per step out of the 80 MB rater-list array, which "
+                         "lives in the Infinity Cache (it cannot live in the 4 MB L2s) — and the drain is bound by the memory LATENCIES a wave's "
+                         "window of ~23 pieces pays one after the other, not by bytes or instruction issue.  Evidence (DESIGN.md section 4, "
+                         "profiles/README.md): round 3 removed the dummy look-ahead group the drain used to wait for at the end of every window: "
+                         "25.7 -> 24.5 ms; pieces aligned to 256 B (two cache lines instead of three, 12 % more pieces): 26.4 ms; 8 -> 6 VALU per "
+                         "piece: the marginal rate per pair product did not move (4.2e-13 s, head sweeps 256 .. 640); every piece read out of the "
+                         "array's first 16 KiB (timing-only): -2.2 ms of ~11.  Timing-only ablations of the round-2 build at H = 384 (26.7 ms "
+                         "kernel): no tail machinery 11.5 ms, + tail set-up and read-out 15.6, + the drain 26.7.  SQ pass of profiles/"
+                         + PMC_PROFILE + ": VALU issue and waiting fractions.  HBM frac on compulsory bytes and the LDS-atomic frac are both reported")
         stage_of = {"k_gemm_nt_bf16": "gemm_ms", "k_tail_select": "select_ms", "k_rerank": "rerank_ms", "k_predict_knn": "predict_ms"}
         dominant = max(stage_of, key=lambda n: tm[stage_of[n]])
         out = {
