@@ -417,6 +417,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_predict_knn_rows(PredArgs A, int
     }
 }
 
+#ifndef KNNCF_PRED_G5
+#define KNNCF_PRED_G5 2  // rows in flight per wave of k_predict_knn_items at 257 .. 320 neighbours (A/B switch)
+#endif
 #ifndef KNNCF_PRED_CHUNK
 #define KNNCF_PRED_CHUNK 64  // test rows per workgroup of k_predict_knn_items (A/B switch; at most 256)
 #endif
@@ -829,7 +832,7 @@ void launch_predict(const Train& tr, NeighborTable* nt, int predictor, int64_t n
             if (trips <= 1) KN_LAUNCH_ITEMS(1, 4);
             else if (trips <= 2) KN_LAUNCH_ITEMS(2, 4);
             else if (trips <= 4) KN_LAUNCH_ITEMS(4, 2);
-            else if (trips <= 5) KN_LAUNCH_ITEMS(5, 2);
+            else if (trips <= 5) KN_LAUNCH_ITEMS(5, KNNCF_PRED_G5);
             else KN_LAUNCH_ITEMS(8, 1);
 #undef KN_LAUNCH_ITEMS
             KN_HIP(hipGetLastError());
