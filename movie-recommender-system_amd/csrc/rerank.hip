@@ -225,8 +225,12 @@ __device__ __attribute__((noinline)) void sort512_in_registers(double* asim, int
 // LDS plan per shortlist tile.  TILE = 512 (k <= 384, the common case): 256-product wave buffers and u's ratings in LDS up to
 // 512 make a 49 KiB plan, and 85 VGPRs (launch bounds) let THREE workgroups share a CU instead of two — this kernel waits on
 // gathers 60 % of the time, so the extra waves pay: 13.5 -> 11.3 ms at the ml-25m shape.  Larger tiles keep the roomier plan.
-template <int TILE> struct RerankPlan {
-    static constexpr int WBUF = TILE <= 512 ? 256 : 512;       // products per wave buffer
+template <int TILE, bool WIDE = false> struct RerankPlan {
+    // products per wave buffer.  A group of four 64-entry pieces may add 256 products, and the buffer is folded whenever it could
+    // not take them: with exactly 256 that is before every group that follows a hit.  WIDE (336) folds only once more than 80
+    // products are pending — about every second group at the ml-25m shape — and is taken when three workgroups still fit a CU
+    // with it (launch_rerank_tile): 10.17 -> 9.87 ms; 352 no longer fits three workgroups at 59 047 items: 13.0 ms.
+    static constexpr int WBUF = TILE <= 512 ? (WIDE ? 336 : 256) : 512;
     static constexpr int UPRE_LDS = TILE <= 512 ? 512 : 1024;  // u's preprocessed ratings are kept in LDS up to this row length
     static constexpr int WAVES_PER_EU = TILE <= 512 ? 6 : 4;
 };
@@ -268,7 +272,7 @@ __device__ unsigned long long g_rphase[8];
 // fold needs: candidate j's products are [cofs[j], cofs[j+1]).
 static constexpr int PIPE = 8;
 static constexpr int GRP = 4;
-static constexpr int WMETA = 256;  // per-wave LDS words: (cend, cbase)[64] | cofs[65]
+static constexpr int WMETA = 200;  // per-wave LDS words: (cend, cbase)[64] | cofs[65] (193 used)
 static constexpr uint32_t NOT_STARTED = 0xffffffffu;
 
 typedef __attribute__((address_space(3))) uint32_t* lds_u32;
@@ -381,7 +385,7 @@ __device__ __forceinline__ double wave_sims(const Rows& R, lds_cu32x2 bp, PreP u
     return acc;
 }
 
-template <int TILE, bool JAC>
+template <int TILE, bool JAC, bool WIDE>
 __global__ void __launch_bounds__(TPB, RerankPlan<TILE>::WAVES_PER_EU) k_rerank(Rows R, const int64_t* __restrict__ seq, int32_t n_rows,
                                                 const int32_t* __restrict__ row_user, int32_t cap,
                                                 const int32_t* __restrict__ cand_idx, const float* __restrict__ cand_approx,
@@ -395,7 +399,7 @@ __global__ void __launch_bounds__(TPB, RerankPlan<TILE>::WAVES_PER_EU) k_rerank(
     // workgroups behind them take the other rows whole, as ever
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t part[TPB / 64];
-    constexpr int WBUF = RerankPlan<TILE>::WBUF, UPRE_LDS = RerankPlan<TILE>::UPRE_LDS;
+    constexpr int WBUF = RerankPlan<TILE, WIDE>::WBUF, UPRE_LDS = RerankPlan<TILE, WIDE>::UPRE_LDS;
     double* ssim = reinterpret_cast<double*>(smem);            // [TILE]
     double* upre = ssim + TILE;                                // [UPRE_LDS]
     double* wbuf = upre + UPRE_LDS;                            // [4][WBUF]
@@ -627,19 +631,19 @@ __global__ void __launch_bounds__(1024) k_sum_row_entries(int32_t n_rows, const 
     if (threadIdx.x < 3 && part[threadIdx.x]) atomicAdd(total + threadIdx.x, part[threadIdx.x]);
 }
 
-template <int TILE, bool JAC>
-static void launch_rerank_tile(const Rows& R, const Train& tr, NeighborTable& nt, int32_t n_rows, const int32_t* d_row_user,
+template <int TILE, bool JAC, bool WIDE>
+static void launch_rerank_plan(const Rows& R, const Train& tr, NeighborTable& nt, int32_t n_rows, const int32_t* d_row_user,
                                int32_t cap, const int32_t* cand_idx, const float* cand_approx, const int32_t* cand_cnt,
                                const float* cand_eps, double* d_stats, uint32_t* d_row_entries, hipStream_t st, const Slices& sl) {
     const int32_t words = (int32_t)ceil_div(tr.I, 32);
-    constexpr int WBUF = RerankPlan<TILE>::WBUF, UPRE_LDS = RerankPlan<TILE>::UPRE_LDS;
+    constexpr int WBUF = RerankPlan<TILE, WIDE>::WBUF, UPRE_LDS = RerankPlan<TILE, WIDE>::UPRE_LDS;
     const size_t smem = (size_t)TILE * 8 + (size_t)UPRE_LDS * 8 + (size_t)(TPB / 64) * WBUF * 8 + (size_t)TILE * 4 +
                         (size_t)words * 8 + (size_t)(TPB / 64) * WMETA * 4;
     KN_REQUIRE(smem <= 160 * 1024 - 2048, KNNCF_E_UNSUPPORTED, "re-rank: item bitmap does not fit in LDS (too many items)");
     static PerDeviceState lds_state;
-    ensure_dynamic_lds(lds_state, (const void*)k_rerank<TILE, JAC>, smem);
+    ensure_dynamic_lds(lds_state, (const void*)k_rerank<TILE, JAC, WIDE>, smem);
     const int32_t grid = n_rows + sl.n_heavy * (sl.P - 1);
-    k_rerank<TILE, JAC><<<grid, TPB, smem, st>>>(R, nt.seq.p, n_rows, d_row_user, cap, cand_idx, cand_approx, cand_cnt, nt.kcap,
+    k_rerank<TILE, JAC, WIDE><<<grid, TPB, smem, st>>>(R, nt.seq.p, n_rows, d_row_user, cap, cand_idx, cand_approx, cand_cnt, nt.kcap,
                                             nt.kcap, nt.idx.p, nt.sim.p, nt.cnt.p, cand_eps, d_stats, d_row_entries, words, sl);
     k_sum_row_entries<<<(unsigned)ceil_div(n_rows, 1024), 1024, 0, st>>>(n_rows, d_row_entries, cand_cnt, cap, reinterpret_cast<unsigned long long*>(d_stats) + 1);
     KN_HIP(hipGetLastError());
@@ -647,6 +651,23 @@ static void launch_rerank_tile(const Rows& R, const Train& tr, NeighborTable& nt
     KN_HIP(hipStreamSynchronize(st));
     rerank_profile_dump();
 #endif
+}
+
+template <int TILE, bool JAC>
+static void launch_rerank_tile(const Rows& R, const Train& tr, NeighborTable& nt, int32_t n_rows, const int32_t* d_row_user,
+                               int32_t cap, const int32_t* cand_idx, const float* cand_approx, const int32_t* cand_cnt,
+                               const float* cand_eps, double* d_stats, uint32_t* d_row_entries, hipStream_t st, const Slices& sl) {
+    if constexpr (TILE <= 512) {
+        // the wide product buffers only where three workgroups still share a CU with them (160 KiB of LDS, 512-byte granules)
+        const size_t words = (size_t)ceil_div(tr.I, 32);
+        const size_t wide = (size_t)TILE * 12 + (size_t)RerankPlan<TILE, true>::UPRE_LDS * 8 + (size_t)(TPB / 64) * RerankPlan<TILE, true>::WBUF * 8 +
+                            words * 8 + (size_t)(TPB / 64) * WMETA * 4 + 64;
+        if (3 * round_up((int64_t)wide, 512) <= 160 * 1024) {
+            launch_rerank_plan<TILE, JAC, true>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, cand_approx, cand_cnt, cand_eps, d_stats, d_row_entries, st, sl);
+            return;
+        }
+    }
+    launch_rerank_plan<TILE, JAC, false>(R, tr, nt, n_rows, d_row_user, cap, cand_idx, cand_approx, cand_cnt, cand_eps, d_stats, d_row_entries, st, sl);
 }
 
 // ---- heavy rows as slices ---------------------------------------------------------------------------------------------
