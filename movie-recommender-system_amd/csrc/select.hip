@@ -431,8 +431,16 @@ __global__ void __launch_bounds__(TPB, WAVES_PER_EU) k_tail_select(const ST* __r
         P = __builtin_amdgcn_readfirstlane(P);
         ne = __builtin_amdgcn_readfirstlane(ne);
         const uint32_t wv = __builtin_amdgcn_readfirstlane(wave);
+#ifdef KNNCF_TAIL_EVEN_PIECES  /* A/B switch: the pieces dealt evenly, every wave rounds its share up to whole groups itself */
         p_lo = (uint32_t)(((uint64_t)P * wv) / (TPB / 64));
         p_hi = (uint32_t)(((uint64_t)P * (wv + 1)) / (TPB / 64));
+#else
+        // whole GROUPS of TAIL_G pieces are dealt, so that only the last wave's last group is padded with null pieces (every
+        // wave rounding its own share up padded ~4 of ~27 pieces per wave and tile)
+        const uint32_t n_groups = (P + TAIL_G - 1) / TAIL_G;
+        p_lo = min(P, (uint32_t)(((uint64_t)n_groups * wv) / (TPB / 64)) * TAIL_G);
+        p_hi = min(P, (uint32_t)(((uint64_t)n_groups * (wv + 1)) / (TPB / 64)) * TAIL_G);
+#endif
     };
     auto use_tables = [&](int buf) {
         e_b = e_b0 + buf * EMAX;
